@@ -1,0 +1,149 @@
+/*
+ * rayjoin_amd.h -- C ABI of the MI355X-native LSI / PIP query path (librayjoin_amd.so).
+ *
+ * The reference (pwrliang/RayJoin @ /root/reference) has no FFI layer: its seam is C++ virtual
+ * dispatch chosen by the -mode string -- LSI<CONTEXT_T>::{Init,Query,get_xsects,CopyTo}
+ * (src/app/lsi.h:8-43), PIP<CONTEXT_T>::{Init,Query,get_closest_eids} (src/app/pip.h:9-38),
+ * with the per-mode index handed over through QueryConfigLBVH (src/app/query_config.h:24-28) and
+ * built in RunLSIQuery/RunPIPQuery (src/run_query.cu:273-290,422-438).  A "-mode=lbvh" drop-in
+ * therefore needs exactly the entry points below; INTEGRATION.md shows the LSILBVH/PIPLBVH
+ * subclasses a maintainer would write on top of them.
+ *
+ * Conventions
+ *   - every function returns an rj_status (0 = ok) and never throws or aborts;
+ *     rj_last_error_string() describes the last failure on that handle;
+ *   - one handle per device; a handle is not thread-safe, different handles may be used from
+ *     different threads (the reference is single-threaded with one stream, src/context.h:119);
+ *   - plain pointers and sizes only; "_dev" pointers are device memory owned by the CALLER
+ *     (hipMalloc / rj_dev_alloc / a torch tensor's data_ptr), all others are host memory;
+ *   - coordinates are the reference's scaled integers: int64 in [-2^46, 2^46) produced on the
+ *     host by Scaling (src/map/scaling.h:79-93); the library never sees floating-point input;
+ *   - queries are synchronous like the reference's (Query ends with stream.Sync(),
+ *     src/app/lsi_lbvh.h:89, src/app/pip_lbvh.h:136) unless the _async form is used.
+ */
+#ifndef RAYJOIN_AMD_H
+#define RAYJOIN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rj_handle_s* rj_handle;
+
+typedef enum {
+  RJ_OK = 0,
+  RJ_E_INVALID = 1,   /* bad argument / call order (e.g. query before rj_build_lbvh) */
+  RJ_E_HIP = 2,       /* a HIP runtime call failed; see rj_last_error_string */
+  RJ_E_OVERFLOW = 3,  /* result queue capacity exceeded; *n_found holds the true count.
+                         (The reference only asserts here: src/util/queue.h:37.) */
+  RJ_E_NOMEM = 4
+} rj_status;
+
+#define RJ_MISS_EID 0xFFFFFFFFu /* static_cast<index_t>(DONTKNOW), src/app/pip_lbvh.h:44 */
+#define RJ_EXTERIOR_FACE_ID 0   /* src/config.h:8 */
+
+/* dev::Intersection<int64_t> as the reference's queue stores it (src/algo/lsi.h:10-26):
+ * two rational<int64_t> (denominators are always 1 after the narrowing store,
+ * src/util/rational.h:84-85,190-192), eid[2] = (map-0 edge, map-1 edge), 48 bytes. */
+typedef struct {
+  int64_t x_num, x_den;
+  int64_t y_num, y_den;
+  uint32_t eid[2];
+  int32_t mid_point_polygon_id; /* DONTKNOW (-1) */
+  int32_t _pad;
+} rj_xsect;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+/* replaces: Context() + Stream (src/context.h:31-74,119; src/util/stream.h:13-27) */
+int rj_create(int device_id, rj_handle* out);
+int rj_destroy(rj_handle h);
+/* run all work of this handle on a caller-owned hipStream_t (NULL = the handle's own stream) */
+int rj_set_stream(rj_handle h, void* hip_stream);
+int rj_sync(rj_handle h);
+const char* rj_last_error_string(rj_handle h);
+const char* rj_version(void);
+
+/* ---- maps ----------------------------------------------------------------------------- */
+/* replaces: Context::LoadToDevice -> Map::LoadFrom (src/context.h:76-88, src/map/map.h:162-233).
+ * xy: np scaled points (x,y interleaved); row_index[nc+1]: first point of each chain + sentinel;
+ * left/right[nc]: face ids of each chain (truncated to 32 bits like dev::Edge, map.h:45).
+ * Edge eid of chain c, point p is p - c (map.h:200-203).  Host arrays are copied. */
+int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np,
+                  const uint32_t* row_index, const int64_t* left, const int64_t* right,
+                  uint64_t nc);
+int rj_map_num_edges(rj_handle h, int map_id, uint64_t* ne);
+int rj_map_num_points(rj_handle h, int map_id, uint64_t* np);
+/* device pointer to the uploaded scaled points (int64 x,y pairs), owned by the handle */
+int rj_map_points_dev(rj_handle h, int map_id, const int64_t** pts_dev);
+
+/* ---- index ---------------------------------------------------------------------------- */
+/* replaces: FillPrimitivesLBVH + lbvh::bvh::assign/construct (src/tree/primtive.h:34-57,
+ * deps/lbvh/lbvh/bvh.cuh:277-481) as called at src/run_query.cu:273-290,422-438. */
+int rj_build_lbvh(rj_handle h, int base_map_id);
+
+/* ---- LSI ------------------------------------------------------------------------------ */
+/* replaces: LSILBVH::Query (src/app/lsi_lbvh.h:27-98) + Queue::Clear/size (src/util/queue.h).
+ * Intersects query-map edges [query_eid_begin, query_eid_end) with all edges of the base map.
+ * Writes (eid of map 0, eid of map 1) pairs, unordered, into pairs_dev[2*capacity].
+ * The predicate is always evaluated as intersect_test(e1 = map-0 edge, e2 = map-1 edge)
+ * whichever side is indexed, which is -mode=grid's operand order (src/app/lsi_grid.h:103-104). */
+int rj_lsi_query(rj_handle h, int base_map_id, int query_map_id, uint64_t query_eid_begin,
+                 uint64_t query_eid_end, uint64_t capacity, uint32_t* pairs_dev,
+                 uint64_t* n_found);
+/* same without the final count read-back/sync; pair with rj_lsi_query_finish */
+int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t query_eid_begin,
+                       uint64_t query_eid_end, uint64_t capacity, uint32_t* pairs_dev);
+int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found);
+
+/* replaces: the intersection-point half of dev::intersect_test + the narrowing store into
+ * Intersection<int64_t> (src/algo/lsi.h:107-143, src/app/lsi_lbvh.h:71-78).
+ * pairs_dev: n (eid map 0, eid map 1) pairs; out_dev: n rj_xsect records. */
+int rj_lsi_points(rj_handle h, const uint32_t* pairs_dev, uint64_t n, rj_xsect* out_dev);
+
+/* sort n pairs in place by (eid0, eid1) -- the canonical order of the reference's checker
+ * (src/run_overlay.cu:38-52) */
+int rj_sort_pairs(rj_handle h, uint32_t* pairs_dev, uint64_t n);
+
+/* ---- PIP ------------------------------------------------------------------------------ */
+/* replaces: PIPLBVH::Query (src/app/pip_lbvh.h:25-142) and the get_face_id transform
+ * (src/map/map.h:79-87, src/app/map_overlay_lbvh.h:96-104).
+ * pts_dev: n scaled query points, or NULL to use points [pt_begin, pt_begin+n) of the query map
+ * (RunPIPQuery queries every vertex of map 1, src/run_query.cu:346).
+ * closest_eid_dev[n]: eid of the lowest base-map edge above each point, RJ_MISS_EID when none.
+ * face_id_dev[n] (nullable): face below that edge, RJ_EXTERIOR_FACE_ID on a miss. */
+int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
+                 uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev);
+int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
+                       uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev,
+                       int32_t* face_id_dev);
+
+/* ---- measurement ---------------------------------------------------------------------- */
+typedef enum {
+  RJ_T_BUILD = 0,     /* whole rj_build_lbvh */
+  RJ_T_LSI_KERNEL = 1,/* the LSI traversal+predicate kernel of the last rj_lsi_query* */
+  RJ_T_PIP_KERNEL = 2,/* the PIP kernel of the last rj_pip_query* */
+  RJ_T_LSI_POINTS = 3,
+  RJ_T_SORT = 4
+} rj_timer;
+/* HIP-event time (ms) of the last launch of that stage on the handle's stream; syncs. */
+int rj_last_ms(rj_handle h, int which, float* ms);
+/* traversal statistics of the last LSI/PIP query (diagnostic; mirrors the reference's
+ * "Total tests"/"Visited nodes" debug counters, src/app/lsi_lbvh.h:37-42,93-94):
+ * stats[0] = leaf blocks visited, [1] = candidate pairs tested exactly, [2] = nodes expanded,
+ * [3] = box tests in the leaf loop.  Collected only after rj_set_option(h,"stats",1). */
+int rj_last_stats(rj_handle h, uint64_t stats[4]);
+int rj_set_option(rj_handle h, const char* name, int64_t value);
+
+/* ---- device memory helpers (for hosts without their own allocator) -------------------- */
+int rj_dev_alloc(rj_handle h, size_t bytes, void** out_dev);
+int rj_dev_free(rj_handle h, void* dev);
+int rj_memcpy_h2d(rj_handle h, void* dst_dev, const void* src, size_t bytes);
+int rj_memcpy_d2h(rj_handle h, void* dst, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYJOIN_AMD_H */

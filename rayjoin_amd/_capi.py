@@ -1,0 +1,239 @@
+"""ctypes binding of librayjoin_amd.so (include/rayjoin_amd.h).  No torch types cross this
+boundary: device buffers are raw pointers (a torch tensor's data_ptr() or rj_dev_alloc memory).
+
+The library is the only compute path: if it is missing or fails to load, importing the query
+operators raises -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librayjoin_amd.so")
+
+RJ_OK, RJ_E_INVALID, RJ_E_HIP, RJ_E_OVERFLOW, RJ_E_NOMEM = 0, 1, 2, 3, 4
+RJ_T_BUILD, RJ_T_LSI_KERNEL, RJ_T_PIP_KERNEL, RJ_T_LSI_POINTS, RJ_T_SORT = 0, 1, 2, 3, 4
+MISS_EID = 0xFFFFFFFF
+
+XSECT_DTYPE = np.dtype(
+    [("x_num", "<i8"), ("x_den", "<i8"), ("y_num", "<i8"), ("y_den", "<i8"),
+     ("eid", "<u4", (2,)), ("mid_point_polygon_id", "<i4"), ("_pad", "<i4")])
+
+# every symbol include/rayjoin_amd.h declares: name -> (restype, argtypes)
+_vp, _u64, _i64, _int = C.c_void_p, C.c_uint64, C.c_int64, C.c_int
+SYMBOLS = {
+    "rj_create": (_int, [_int, C.POINTER(_vp)]),
+    "rj_destroy": (_int, [_vp]),
+    "rj_set_stream": (_int, [_vp, _vp]),
+    "rj_sync": (_int, [_vp]),
+    "rj_last_error_string": (C.c_char_p, [_vp]),
+    "rj_version": (C.c_char_p, []),
+    "rj_upload_map": (_int, [_vp, _int, _vp, _u64, _vp, _vp, _vp, _u64]),
+    "rj_map_num_edges": (_int, [_vp, _int, C.POINTER(_u64)]),
+    "rj_map_num_points": (_int, [_vp, _int, C.POINTER(_u64)]),
+    "rj_map_points_dev": (_int, [_vp, _int, C.POINTER(_vp)]),
+    "rj_build_lbvh": (_int, [_vp, _int]),
+    "rj_lsi_query": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp, C.POINTER(_u64)]),
+    "rj_lsi_query_async": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp]),
+    "rj_lsi_query_finish": (_int, [_vp, _u64, C.POINTER(_u64)]),
+    "rj_lsi_points": (_int, [_vp, _vp, _u64, _vp]),
+    "rj_sort_pairs": (_int, [_vp, _vp, _u64]),
+    "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
+    "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
+    "rj_last_ms": (_int, [_vp, _int, C.POINTER(C.c_float)]),
+    "rj_last_stats": (_int, [_vp, C.POINTER(_u64)]),
+    "rj_set_option": (_int, [_vp, C.c_char_p, _i64]),
+    "rj_dev_alloc": (_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
+    "rj_dev_free": (_int, [_vp, _vp]),
+    "rj_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "rj_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
+}
+
+
+class RayJoinError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rayjoin_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class QueueOverflow(RayJoinError):
+    """RJ_E_OVERFLOW: n_found holds the true count (the reference only asserts, queue.h:37)."""
+
+    def __init__(self, msg, n_found):
+        super().__init__(RJ_E_OVERFLOW, msg)
+        self.n_found = n_found
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library.  Fails loudly when it has not been built (python -c 'import
+    __graft_entry__ as g; g.build()' or make -C rayjoin_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("rayjoin_amd: %s is missing -- build the HIP extension first "
+                              "(make -C rayjoin_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    """void* of a numpy array (host), an int, None, or anything with data_ptr() (torch tensor)."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    return a.ctypes.data
+
+
+class DeviceBuffer:
+    """Device memory owned through the C ABI (rj_dev_alloc) for hosts without torch."""
+
+    def __init__(self, handle, nbytes):
+        self.handle = handle
+        self.nbytes = int(nbytes)
+        p = _vp()
+        handle._check(load().rj_dev_alloc(handle.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def data_ptr(self):
+        return self.ptr
+
+    def to_host(self, dtype, count=None):
+        dtype = np.dtype(dtype)
+        count = self.nbytes // dtype.itemsize if count is None else int(count)
+        out = np.empty(count, dtype=dtype)
+        if count:
+            self.handle._check(load().rj_memcpy_d2h(self.handle.h, out.ctypes.data, self.ptr,
+                                                    count * dtype.itemsize))
+        return out
+
+    def from_host(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        if arr.nbytes:
+            self.handle._check(load().rj_memcpy_h2d(self.handle.h, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            load().rj_dev_free(self.handle.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.handle.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class Handle:
+    """One per GPU (rj_create).  Thin, 1:1 with the C ABI."""
+
+    def __init__(self, device_id=0):
+        self.L = load()
+        h = _vp()
+        rc = self.L.rj_create(int(device_id), C.byref(h))
+        if rc != RJ_OK:
+            raise RayJoinError(rc, "rj_create(device %d) failed -- no usable HIP device?" % device_id)
+        self.h = h.value
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rj_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != RJ_OK:
+            raise RayJoinError(rc, self.L.rj_last_error_string(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._check(self.L.rj_set_stream(self.h, stream_ptr))
+
+    def sync(self):
+        self._check(self.L.rj_sync(self.h))
+
+    def set_option(self, name, value):
+        self._check(self.L.rj_set_option(self.h, name.encode(), int(value)))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def upload_map(self, map_id, pts, row_index, left, right):
+        pts = np.ascontiguousarray(pts, dtype=np.int64).reshape(-1, 2)
+        row_index = np.ascontiguousarray(row_index, dtype=np.uint32)
+        left = np.ascontiguousarray(left, dtype=np.int64)
+        right = np.ascontiguousarray(right, dtype=np.int64)
+        nc = left.shape[0]
+        self._check(self.L.rj_upload_map(self.h, map_id, pts.ctypes.data, pts.shape[0],
+                                         row_index.ctypes.data, left.ctypes.data, right.ctypes.data, nc))
+
+    def map_num_edges(self, map_id):
+        n = _u64()
+        self._check(self.L.rj_map_num_edges(self.h, map_id, C.byref(n)))
+        return n.value
+
+    def map_num_points(self, map_id):
+        n = _u64()
+        self._check(self.L.rj_map_num_points(self.h, map_id, C.byref(n)))
+        return n.value
+
+    def map_points_dev(self, map_id):
+        p = _vp()
+        self._check(self.L.rj_map_points_dev(self.h, map_id, C.byref(p)))
+        return p.value
+
+    def build_lbvh(self, base_map_id):
+        self._check(self.L.rj_build_lbvh(self.h, base_map_id))
+
+    def lsi_query(self, base_map_id, query_map_id, qb, qe, capacity, pairs_dev):
+        n = _u64()
+        rc = self.L.rj_lsi_query(self.h, base_map_id, query_map_id, qb, qe, capacity, _ptr(pairs_dev), C.byref(n))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
+        self._check(rc)
+        return n.value
+
+    def lsi_query_async(self, base_map_id, query_map_id, qb, qe, capacity, pairs_dev):
+        self._check(self.L.rj_lsi_query_async(self.h, base_map_id, query_map_id, qb, qe, capacity, _ptr(pairs_dev)))
+
+    def lsi_query_finish(self, capacity):
+        n = _u64()
+        rc = self.L.rj_lsi_query_finish(self.h, capacity, C.byref(n))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
+        self._check(rc)
+        return n.value
+
+    def lsi_points(self, pairs_dev, n, out_dev):
+        self._check(self.L.rj_lsi_points(self.h, _ptr(pairs_dev), n, _ptr(out_dev)))
+
+    def sort_pairs(self, pairs_dev, n):
+        self._check(self.L.rj_sort_pairs(self.h, _ptr(pairs_dev), n))
+
+    def pip_query(self, base_map_id, query_map_id, pts_dev, pt_begin, n, closest_dev, face_dev=None, sync=True):
+        fn = self.L.rj_pip_query if sync else self.L.rj_pip_query_async
+        self._check(fn(self.h, base_map_id, query_map_id, _ptr(pts_dev), pt_begin, n, _ptr(closest_dev), _ptr(face_dev)))
+
+    def last_ms(self, which):
+        ms = C.c_float()
+        self._check(self.L.rj_last_ms(self.h, which, C.byref(ms)))
+        return ms.value
+
+    def last_stats(self):
+        s = (_u64 * 4)()
+        self._check(self.L.rj_last_stats(self.h, s))
+        return dict(leaf_blocks=s[0], exact_tests=s[1], nodes_expanded=s[2], leaf_box_tests=s[3])

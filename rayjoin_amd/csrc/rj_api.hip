@@ -1,0 +1,499 @@
+// rj_api.hip -- the C ABI of include/rayjoin_amd.h on top of the kernels in rj_kernels.hip.
+// Host-side orchestration only (allocation, upload, launch order, timing events).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rayjoin_amd.h"
+#include "rj_kernels.h"
+
+using namespace rj;
+
+namespace {
+
+struct MapState {
+  bool present = false;
+  uint64_t np = 0, ne = 0, nc = 0;
+  int64_t* pts = nullptr;
+  Seg* seg = nullptr;
+  uint32_t* edge_chain = nullptr;
+  uint32_t* left = nullptr;
+  uint32_t* right = nullptr;
+};
+
+struct BvhState {
+  bool built = false;
+  uint64_t n0 = 0, n0p = 0;
+  Seg* sseg = nullptr;
+  uint32_t* seid = nullptr;
+  QBox* box0 = nullptr;
+  QBox* lvl[kMaxLevels] = {nullptr};
+  uint64_t nlvl[kMaxLevels] = {0};
+  uint64_t alloc[kMaxLevels] = {0};
+  int top = 0;
+};
+
+constexpr int kNumTimers = 5;
+
+}  // namespace
+
+struct rj_handle_s {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  MapState map[2];
+  BvhState bvh[2];
+  unsigned long long* d_counter = nullptr;  // [1] LSI result count
+  unsigned long long* d_stats = nullptr;    // [4]
+  unsigned long long* h_pinned = nullptr;   // [8] pinned read-back area
+  hipEvent_t ev[kNumTimers][2];
+  bool ev_valid[kNumTimers] = {false};
+  bool stats_on = false;
+  int max_blocks = 256 * 8;  // 256 CUs x 8 blocks of 256 threads
+  uint64_t last_stats[4] = {0, 0, 0, 0};
+  std::string err;
+};
+
+namespace {
+
+int fail(rj_handle h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define RJ_HIP(h, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(h, _e == hipErrorOutOfMemory ? RJ_E_NOMEM : RJ_E_HIP, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+#define RJ_CHECK_H(h) \
+  if (!(h)) return RJ_E_INVALID
+
+template <typename T>
+int dev_alloc(rj_handle h, T** p, uint64_t count) {
+  *p = nullptr;
+  RJ_HIP(h, hipMalloc((void**) p, (count ? count : 1) * sizeof(T)));
+  return RJ_OK;
+}
+
+void free_map(MapState& m) {
+  (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.left); (void) hipFree(m.right);
+  m = MapState();
+}
+
+void free_bvh(BvhState& b) {
+  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.box0);
+  for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
+  b = BvhState();
+}
+
+DeviceBvh bvh_view(const BvhState& b) {
+  DeviceBvh d;
+  d.sseg = b.sseg; d.seid = b.seid; d.box0 = b.box0;
+  for (int l = 0; l < kMaxLevels; l++) { d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l]; }
+  d.top = b.top; d.n0 = b.n0;
+  return d;
+}
+
+DeviceMap map_view(const MapState& m) {
+  DeviceMap d;
+  d.pts = m.pts; d.seg = m.seg; d.edge_chain = m.edge_chain; d.left = m.left; d.right = m.right;
+  d.np = m.np; d.ne = m.ne; d.nc = m.nc;
+  return d;
+}
+
+int set_device(rj_handle h) {
+  RJ_HIP(h, hipSetDevice(h->device));
+  return RJ_OK;
+}
+
+void tic(rj_handle h, int t) { (void) hipEventRecord(h->ev[t][0], h->stream); }
+void toc(rj_handle h, int t) { (void) hipEventRecord(h->ev[t][1], h->stream); h->ev_valid[t] = true; }
+
+uint64_t pad64(uint64_t n) { return (n + 63) / 64 * 64; }
+
+}  // namespace
+
+extern "C" {
+
+const char* rj_version(void) { return "rayjoin_amd 0.1.0 (gfx950)"; }
+
+int rj_create(int device_id, rj_handle* out) {
+  if (!out) return RJ_E_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return RJ_E_HIP;
+  rj_handle h = new (std::nothrow) rj_handle_s();
+  if (!h) return RJ_E_NOMEM;
+  h->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess) { delete h; return RJ_E_HIP; }
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RJ_E_HIP; }
+  h->stream = h->own_stream;
+  bool ok = hipMalloc((void**) &h->d_counter, 8) == hipSuccess &&
+            hipMalloc((void**) &h->d_stats, 32) == hipSuccess &&
+            hipHostMalloc((void**) &h->h_pinned, 64) == hipSuccess;
+  for (int t = 0; ok && t < kNumTimers; t++)
+    ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
+  if (!ok) { delete h; return RJ_E_HIP; }
+  *out = h;
+  return RJ_OK;
+}
+
+int rj_destroy(rj_handle h) {
+  RJ_CHECK_H(h);
+  (void) hipSetDevice(h->device);
+  (void) hipStreamSynchronize(h->stream);
+  for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); }
+  (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned);
+  for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
+  (void) hipStreamDestroy(h->own_stream);
+  delete h;
+  return RJ_OK;
+}
+
+int rj_set_stream(rj_handle h, void* s) {
+  RJ_CHECK_H(h);
+  h->stream = s ? (hipStream_t) s : h->own_stream;
+  return RJ_OK;
+}
+
+int rj_sync(rj_handle h) {
+  RJ_CHECK_H(h);
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  return RJ_OK;
+}
+
+const char* rj_last_error_string(rj_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int rj_set_option(rj_handle h, const char* name, int64_t value) {
+  RJ_CHECK_H(h);
+  if (!name) return fail(h, RJ_E_INVALID, "null option name");
+  if (!strcmp(name, "stats")) { h->stats_on = value != 0; return RJ_OK; }
+  if (!strcmp(name, "max_blocks")) {
+    if (value < 1 || value > 65536) return fail(h, RJ_E_INVALID, "max_blocks out of range");
+    h->max_blocks = (int) value;
+    return RJ_OK;
+  }
+  return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
+}
+
+int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const uint32_t* row_index,
+                  const int64_t* left, const int64_t* right, uint64_t nc) {
+  RJ_CHECK_H(h);
+  if (map_id < 0 || map_id > 1) return fail(h, RJ_E_INVALID, "map_id must be 0 or 1");
+  if ((np && !xy) || (nc && (!row_index || !left || !right))) return fail(h, RJ_E_INVALID, "null input array");
+  if (np >= (1ull << 32) || nc > np) return fail(h, RJ_E_INVALID, "index_t is 32-bit: np < 2^32, nc <= np");
+  if (nc && (row_index[0] != 0 || row_index[nc] != np)) return fail(h, RJ_E_INVALID, "row_index must start at 0 and end at np");
+  for (uint64_t c = 0; c < nc; c++)
+    if (row_index[c + 1] < row_index[c] + 2)
+      return fail(h, RJ_E_INVALID, "chain %llu has fewer than 2 points (planar_graph.h:71)", (unsigned long long) c);
+  if (nc == 0 && np != 0) return fail(h, RJ_E_INVALID, "points without chains");
+  for (uint64_t i = 0; i < 2 * np; i++)
+    if (xy[i] < -((int64_t) 1 << 46) || xy[i] >= ((int64_t) 1 << 46))
+      return fail(h, RJ_E_INVALID, "coordinate %llu outside the scaled range [-2^46, 2^46)", (unsigned long long) i);
+  if (int r = set_device(h)) return r;
+  MapState& m = h->map[map_id];
+  free_map(m);
+  free_bvh(h->bvh[map_id]);
+  m.np = np; m.nc = nc; m.ne = np - nc;
+  if (int r = dev_alloc(h, &m.pts, 2 * np + 2)) return r;
+  if (int r = dev_alloc(h, &m.seg, m.ne)) return r;
+  if (int r = dev_alloc(h, &m.edge_chain, m.ne)) return r;
+  if (int r = dev_alloc(h, &m.left, nc)) return r;
+  if (int r = dev_alloc(h, &m.right, nc)) return r;
+  std::vector<uint32_t> eb(nc + 1), l32(nc), r32(nc);
+  for (uint64_t c = 0; c <= nc; c++) eb[c] = nc ? (uint32_t) (row_index[c] - c) : 0;
+  for (uint64_t c = 0; c < nc; c++) { l32[c] = (uint32_t) left[c]; r32[c] = (uint32_t) right[c]; }  // map.h:45
+  uint32_t* d_eb = nullptr;
+  if (int r = dev_alloc(h, &d_eb, nc + 1)) return r;
+  hipError_t e = hipSuccess;
+  if (np) e = hipMemcpyAsync(m.pts, xy, 16 * np, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && nc) e = hipMemcpyAsync(d_eb, eb.data(), 4 * (nc + 1), hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && nc) e = hipMemcpyAsync(m.left, l32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess && nc) e = hipMemcpyAsync(m.right, r32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
+  if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, d_eb, (uint32_t) nc, m.ne, m.seg, m.edge_chain);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void) hipFree(d_eb);
+  RJ_HIP(h, e);
+  m.present = true;
+  return RJ_OK;
+}
+
+int rj_map_num_edges(rj_handle h, int map_id, uint64_t* ne) {
+  RJ_CHECK_H(h);
+  if (map_id < 0 || map_id > 1 || !ne || !h->map[map_id].present) return fail(h, RJ_E_INVALID, "map not uploaded");
+  *ne = h->map[map_id].ne;
+  return RJ_OK;
+}
+
+int rj_map_num_points(rj_handle h, int map_id, uint64_t* np) {
+  RJ_CHECK_H(h);
+  if (map_id < 0 || map_id > 1 || !np || !h->map[map_id].present) return fail(h, RJ_E_INVALID, "map not uploaded");
+  *np = h->map[map_id].np;
+  return RJ_OK;
+}
+
+int rj_map_points_dev(rj_handle h, int map_id, const int64_t** pts_dev) {
+  RJ_CHECK_H(h);
+  if (map_id < 0 || map_id > 1 || !pts_dev || !h->map[map_id].present) return fail(h, RJ_E_INVALID, "map not uploaded");
+  *pts_dev = h->map[map_id].pts;
+  return RJ_OK;
+}
+
+int rj_build_lbvh(rj_handle h, int base_map_id) {
+  RJ_CHECK_H(h);
+  if (base_map_id < 0 || base_map_id > 1 || !h->map[base_map_id].present)
+    return fail(h, RJ_E_INVALID, "rj_build_lbvh: map %d not uploaded", base_map_id);
+  if (int r = set_device(h)) return r;
+  const MapState& m = h->map[base_map_id];
+  BvhState& b = h->bvh[base_map_id];
+  free_bvh(b);
+  tic(h, RJ_T_BUILD);
+  b.n0 = m.ne;
+  b.n0p = pad64(m.ne ? m.ne : 1);
+  // level sizes: level l has ceil(n_{l-1}/64) nodes; top = first level with <= 64 nodes
+  b.nlvl[0] = b.n0;
+  b.alloc[0] = b.n0p;
+  int top = 0;
+  uint64_t n = b.n0p / 64;  // number of leaf blocks (>= 1)
+  for (int l = 1; l < kMaxLevels; l++) {
+    b.nlvl[l] = n;
+    b.alloc[l] = pad64(n);
+    top = l;
+    if (n <= 64) break;
+    n = (n + 63) / 64;
+  }
+  if (b.nlvl[top] > 64) return fail(h, RJ_E_INVALID, "too many segments for %d levels", kMaxLevels);
+  b.top = top;
+  if (int r = dev_alloc(h, &b.sseg, b.n0p)) return r;
+  if (int r = dev_alloc(h, &b.seid, b.n0p)) return r;
+  if (int r = dev_alloc(h, &b.box0, b.n0p)) return r;
+  for (int l = 1; l <= top; l++)
+    if (int r = dev_alloc(h, &b.lvl[l], b.alloc[l])) return r;
+  // 1. Morton keys  2. radix sort (key, eid)  3. gather into sorted order + leaf boxes  4. levels
+  uint64_t *k_in = nullptr, *k_out = nullptr;
+  uint32_t *v_in = nullptr, *v_out = nullptr;
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  int rc = RJ_OK;
+  hipError_t e = hipSuccess;
+  do {
+    if ((rc = dev_alloc(h, &k_in, m.ne))) break;
+    if ((rc = dev_alloc(h, &k_out, m.ne))) break;
+    if ((rc = dev_alloc(h, &v_in, m.ne))) break;
+    if ((rc = dev_alloc(h, &v_out, m.ne))) break;
+    if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
+    if (m.ne) {
+      if ((e = sort_pairs_u64_u32(h->stream, nullptr, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
+      if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1)) != hipSuccess) break;
+      if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
+    }
+    if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.ne, b.n0p, b.sseg, b.seid, b.box0)) != hipSuccess) break;
+    const QBox* child = b.box0;
+    uint64_t child_alloc = b.n0p;
+    for (int l = 1; l <= top; l++) {
+      if ((e = launch_reduce_level(h->stream, child, child_alloc, b.lvl[l], b.alloc[l])) != hipSuccess) break;
+      child = b.lvl[l];
+      child_alloc = b.alloc[l];
+    }
+    if (e != hipSuccess) break;
+    toc(h, RJ_T_BUILD);
+    e = hipStreamSynchronize(h->stream);
+  } while (0);
+  (void) hipFree(k_in); (void) hipFree(k_out); (void) hipFree(v_in); (void) hipFree(v_out); (void) hipFree(temp);
+  if (rc) return rc;
+  RJ_HIP(h, e);
+  b.built = true;
+  return RJ_OK;
+}
+
+static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
+                      uint64_t capacity, uint32_t* pairs_dev) {
+  if (base_map_id < 0 || base_map_id > 1 || query_map_id != 1 - base_map_id)
+    return fail(h, RJ_E_INVALID, "rj_lsi_query: base/query map ids must be {0,1} and differ");
+  if (!h->map[query_map_id].present) return fail(h, RJ_E_INVALID, "rj_lsi_query: query map not uploaded");
+  if (!h->bvh[base_map_id].built) return fail(h, RJ_E_INVALID, "rj_lsi_query: call rj_build_lbvh(base map) first");
+  if (qb > qe || qe > h->map[query_map_id].ne) return fail(h, RJ_E_INVALID, "rj_lsi_query: bad query eid range");
+  if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query: null output");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear (queue.h:125-129)
+  if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 32, h->stream));
+  LsiArgs a;
+  a.bvh = bvh_view(h->bvh[base_map_id]);
+  a.qseg = h->map[query_map_id].seg;
+  a.qbeg = qb; a.qend = qe;
+  a.base_is_map0 = base_map_id == 0;
+  a.out = pairs_dev; a.cap = capacity;
+  a.counter = h->d_counter;
+  a.stats = h->stats_on ? h->d_stats : nullptr;
+  tic(h, RJ_T_LSI_KERNEL);
+  if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, h->max_blocks));
+  toc(h, RJ_T_LSI_KERNEL);
+  return RJ_OK;
+}
+
+int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
+                       uint64_t capacity, uint32_t* pairs_dev) {
+  RJ_CHECK_H(h);
+  return lsi_launch(h, base_map_id, query_map_id, qb, qe, capacity, pairs_dev);
+}
+
+int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
+  RJ_CHECK_H(h);
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter, 8, hipMemcpyDeviceToHost, h->stream));
+  if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 32, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  uint64_t n = h->h_pinned[0];
+  if (h->stats_on) for (int i = 0; i < 4; i++) h->last_stats[i] = h->h_pinned[1 + i];
+  if (n_found) *n_found = n;
+  if (n > capacity)
+    return fail(h, RJ_E_OVERFLOW, "intersection queue overflow: %llu found, capacity %llu",
+                (unsigned long long) n, (unsigned long long) capacity);
+  return RJ_OK;
+}
+
+int rj_lsi_query(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
+                 uint64_t capacity, uint32_t* pairs_dev, uint64_t* n_found) {
+  RJ_CHECK_H(h);
+  if (int r = lsi_launch(h, base_map_id, query_map_id, qb, qe, capacity, pairs_dev)) return r;
+  return rj_lsi_query_finish(h, capacity, n_found);
+}
+
+int rj_lsi_points(rj_handle h, const uint32_t* pairs_dev, uint64_t n, rj_xsect* out_dev) {
+  RJ_CHECK_H(h);
+  if (!h->map[0].present || !h->map[1].present) return fail(h, RJ_E_INVALID, "rj_lsi_points: both maps must be uploaded");
+  if (n && (!pairs_dev || !out_dev)) return fail(h, RJ_E_INVALID, "rj_lsi_points: null buffer");
+  if (int r = set_device(h)) return r;
+  tic(h, RJ_T_LSI_POINTS);
+  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, (XsectRec*) out_dev));
+  toc(h, RJ_T_LSI_POINTS);
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  return RJ_OK;
+}
+
+int rj_sort_pairs(rj_handle h, uint32_t* pairs_dev, uint64_t n) {
+  RJ_CHECK_H(h);
+  if (n == 0) return RJ_OK;
+  if (!pairs_dev) return fail(h, RJ_E_INVALID, "rj_sort_pairs: null buffer");
+  if (int r = set_device(h)) return r;
+  uint64_t* keys = (uint64_t*) pairs_dev;  // little-endian (eid0, eid1) -> swap so eid0 is the high word
+  uint64_t* tmp = nullptr;
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  if (int r = dev_alloc(h, &tmp, n)) return r;
+  tic(h, RJ_T_SORT);
+  hipError_t e = launch_swap_halves(h->stream, keys, n);
+  if (e == hipSuccess) e = sort_keys_u64(h->stream, nullptr, temp_bytes, keys, tmp, n);
+  if (e == hipSuccess) e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1);
+  if (e == hipSuccess) e = sort_keys_u64(h->stream, temp, temp_bytes, keys, tmp, n);
+  if (e == hipSuccess) e = hipMemcpyAsync(keys, tmp, 8 * n, hipMemcpyDeviceToDevice, h->stream);
+  if (e == hipSuccess) e = launch_swap_halves(h->stream, keys, n);
+  toc(h, RJ_T_SORT);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void) hipFree(tmp); (void) hipFree(temp);
+  RJ_HIP(h, e);
+  return RJ_OK;
+}
+
+int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
+                       uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev) {
+  RJ_CHECK_H(h);
+  if (base_map_id < 0 || base_map_id > 1 || query_map_id != 1 - base_map_id)
+    return fail(h, RJ_E_INVALID, "rj_pip_query: base/query map ids must be {0,1} and differ");
+  if (!h->bvh[base_map_id].built) return fail(h, RJ_E_INVALID, "rj_pip_query: call rj_build_lbvh(base map) first");
+  if (n && !closest_eid_dev) return fail(h, RJ_E_INVALID, "rj_pip_query: null output");
+  const int64_t* pts = pts_dev;
+  if (!pts) {
+    const MapState& q = h->map[query_map_id];
+    if (!q.present || pt_begin + n > q.np) return fail(h, RJ_E_INVALID, "rj_pip_query: bad point range of the query map");
+    pts = q.pts + 2 * pt_begin;
+  }
+  if (int r = set_device(h)) return r;
+  if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 32, h->stream));
+  PipArgs a;
+  a.bvh = bvh_view(h->bvh[base_map_id]);
+  a.base = map_view(h->map[base_map_id]);
+  a.pts = pts; a.n = n;
+  a.query_map_id = query_map_id;
+  a.closest = closest_eid_dev; a.face = face_id_dev;
+  a.stats = h->stats_on ? h->d_stats : nullptr;
+  tic(h, RJ_T_PIP_KERNEL);
+  if (n) RJ_HIP(h, launch_pip(h->stream, a, h->stats_on, h->max_blocks));
+  toc(h, RJ_T_PIP_KERNEL);
+  return RJ_OK;
+}
+
+int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
+                 uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev) {
+  RJ_CHECK_H(h);
+  if (int r = rj_pip_query_async(h, base_map_id, query_map_id, pts_dev, pt_begin, n, closest_eid_dev, face_id_dev)) return r;
+  if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 32, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  if (h->stats_on) for (int i = 0; i < 4; i++) h->last_stats[i] = h->h_pinned[1 + i];
+  return RJ_OK;
+}
+
+int rj_last_ms(rj_handle h, int which, float* ms) {
+  RJ_CHECK_H(h);
+  if (which < 0 || which >= kNumTimers || !ms) return fail(h, RJ_E_INVALID, "rj_last_ms: bad timer");
+  if (!h->ev_valid[which]) return fail(h, RJ_E_INVALID, "rj_last_ms: stage %d has not run", which);
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipEventSynchronize(h->ev[which][1]));
+  RJ_HIP(h, hipEventElapsedTime(ms, h->ev[which][0], h->ev[which][1]));
+  return RJ_OK;
+}
+
+int rj_last_stats(rj_handle h, uint64_t stats[4]) {
+  RJ_CHECK_H(h);
+  if (!stats) return fail(h, RJ_E_INVALID, "null stats");
+  for (int i = 0; i < 4; i++) stats[i] = h->last_stats[i];
+  return RJ_OK;
+}
+
+int rj_dev_alloc(rj_handle h, size_t bytes, void** out_dev) {
+  RJ_CHECK_H(h);
+  if (!out_dev) return fail(h, RJ_E_INVALID, "null out pointer");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipMalloc(out_dev, bytes ? bytes : 1));
+  return RJ_OK;
+}
+
+int rj_dev_free(rj_handle h, void* dev) {
+  RJ_CHECK_H(h);
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipFree(dev));
+  return RJ_OK;
+}
+
+int rj_memcpy_h2d(rj_handle h, void* dst_dev, const void* src, size_t bytes) {
+  RJ_CHECK_H(h);
+  if (int r = set_device(h)) return r;
+  if (bytes) RJ_HIP(h, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  return RJ_OK;
+}
+
+int rj_memcpy_d2h(rj_handle h, void* dst, const void* src_dev, size_t bytes) {
+  RJ_CHECK_H(h);
+  if (int r = set_device(h)) return r;
+  if (bytes) RJ_HIP(h, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  return RJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,92 @@
+// rj_device.h -- device-side layout of maps and of the wave64-native implicit LBVH,
+// plus the wave-level helpers every kernel uses.  gfx950 only (wave = 64 lanes).
+//
+// LBVH layout (replaces deps/lbvh's pointer-based binary Karras tree, deps/lbvh/lbvh/bvh.cuh:
+// tree shape does not affect results, only the exact predicate does -- SURVEY fact 8):
+//   * base segments are sorted by a 64-bit 2-D Morton key of their midpoint (y is the
+//     most significant interleaved bit so the first children of a node are its low-y half);
+//   * level 0 = the sorted segments, level l = groups of 64 consecutive level-(l-1) nodes:
+//     a 64-ary, pointer-free, implicit tree.  Node i of level l covers children
+//     [64 i, 64 i + 64) of level l-1, so ONE wave tests all children of a node with one
+//     coalesced 1 KiB load and one __ballot;
+//   * boxes are conservative 31-bit integer boxes: q(v) = (v + 2^46) >> 16.  floor() is monotone,
+//     so real closed-interval overlap implies quantised overlap; the exact predicate decides.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rj_predicates.h"
+
+namespace rj {
+
+constexpr int kWave = 64;
+constexpr int kMaxLevels = 6;          // levels 1..5 suffice for 2^32 segments (64^5 = 2^30 leaves blocks)
+constexpr int kStackEntries = 64 * 5 + 64;
+constexpr int kPairBuf = 128;          // >= 64 (carry) + 64 (one append step)
+constexpr int kQuantShift = 16;
+constexpr int64_t kCoordOffset = (int64_t) 1 << 46;
+constexpr int32_t kEmptyMin = 0x7FFFFFFF;
+constexpr int32_t kEmptyMax = -1;
+
+struct QBox {  // 16 bytes: one dwordx4 load
+  int32_t x0, y0, x1, y1;
+};
+
+struct DeviceMap {
+  const int64_t* pts;         // [np][2]
+  const Seg* seg;             // [ne] in eid order
+  const uint32_t* edge_chain; // [ne]
+  const uint32_t* left;       // [nc]
+  const uint32_t* right;      // [nc]
+  uint64_t np, ne, nc;
+};
+
+struct DeviceBvh {
+  const Seg* sseg;        // [n0p] segments in Morton order (padding = zero segments)
+  const uint32_t* seid;   // [n0p] original eid of each sorted slot
+  const QBox* box0;       // [n0p] per-segment boxes (padding = empty)
+  const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
+  uint32_t nlvl[kMaxLevels];    // real node count per level
+  int top;                // top level: nlvl[top] <= 64
+  uint64_t n0;            // real segment count
+};
+
+__device__ __forceinline__ int lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
+}
+// number of set bits of m below this lane
+__device__ __forceinline__ int rank_below(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0));
+}
+__device__ __forceinline__ int32_t quant(int64_t v) { return (int32_t) ((v + kCoordOffset) >> kQuantShift); }
+
+__device__ __forceinline__ int32_t wave_min(int32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int32_t t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int32_t wave_max(int32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int32_t t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+__device__ __forceinline__ int32_t bcast(int32_t v, int src_lane_uniform) {
+  return __builtin_amdgcn_readlane(v, src_lane_uniform);
+}
+// compiler-level ordering of LDS traffic between lanes of one wave (hardware executes a wave's
+// DS instructions in order; this only stops the compiler from reordering/caching them)
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ bool overlap(const QBox& a, int32_t bx0, int32_t by0, int32_t bx1, int32_t by1) {
+  return a.x0 <= bx1 && bx0 <= a.x1 && a.y0 <= by1 && by0 <= a.y1;
+}
+
+}  // namespace rj

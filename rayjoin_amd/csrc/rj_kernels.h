@@ -1,0 +1,54 @@
+// rj_kernels.h -- kernel argument blocks and launch wrappers (implemented in rj_kernels.hip)
+#pragma once
+#include "rj_device.h"
+
+namespace rj {
+
+struct XsectRec {  // == rj_xsect (include/rayjoin_amd.h) == dev::Intersection<int64_t>, 48 bytes
+  int64_t x_num, x_den, y_num, y_den;
+  uint32_t eid0, eid1;
+  int32_t mid, pad;
+};
+static_assert(sizeof(XsectRec) == 48, "Intersection record must be 48 bytes");
+static_assert(sizeof(Seg) == 32 && sizeof(QBox) == 16, "layout");
+
+struct LsiArgs {
+  DeviceBvh bvh;
+  const Seg* qseg;     // query map segments in eid order
+  uint64_t qbeg, qend; // query eid range
+  int base_is_map0;
+  uint32_t* out;       // pairs out [2*cap]
+  uint64_t cap;
+  unsigned long long* counter;  // result count
+  unsigned long long* stats;    // [4] or nullptr
+};
+
+struct PipArgs {
+  DeviceBvh bvh;
+  DeviceMap base;
+  const int64_t* pts;  // query points (x,y interleaved), already offset to the first point
+  uint64_t n;
+  int query_map_id;
+  uint32_t* closest;   // [n]
+  int32_t* face;       // [n] or nullptr
+  unsigned long long* stats;
+};
+
+hipError_t launch_build_segs(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin,
+                             uint32_t nc, uint64_t ne, Seg* seg, uint32_t* edge_chain);
+hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, uint64_t* keys, uint32_t* vals);
+hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
+                              uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n);
+hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
+                         uint64_t* kout, uint64_t n);
+hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
+hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, uint64_t ne,
+                                uint64_t n0p, Seg* sseg, uint32_t* seid, QBox* box0);
+hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
+                               uint64_t n_parent_alloc);
+hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks);
+hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
+                             uint64_t n, XsectRec* out);
+hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
+
+}  // namespace rj

@@ -1,0 +1,203 @@
+// rj_predicates.h -- exact-arithmetic LSI / PIP predicates, shared by every HIP kernel.
+//
+// Numerically identical to the reference (file:line relative to /root/reference):
+//   lsi_test()      dev::intersect_test, boolean form            src/algo/lsi.h:29-103
+//   lsi_point()     intersection point + narrowing store         src/algo/lsi.h:107-143,
+//                                                                 src/util/rational.h:87-90,190-203,335-343
+//   pip_eval()/pip_better()  "lowest edge above point" predicate  src/algo/pip.h:31-96
+//                                                                 == src/app/pip_lbvh.h:57-123
+// The 80-byte dev::Edge (src/map/map.h:20-46) is never stored: a, b, c are rebuilt from the two
+// endpoints (map.h:216-226), which is cheaper than a 48-byte gather on a latency-bound path.
+//
+// RJ_HD lets tests compile these functions for the host (tests/hosttwin) -- a test-only twin,
+// never a fallback: the product path is HIP only.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define RJ_HD __host__ __device__ __forceinline__
+#else
+#define RJ_HD inline
+#endif
+
+namespace rj {
+
+typedef __int128 i128;
+typedef unsigned __int128 u128;
+
+struct Seg {  // scaled endpoints, 32 bytes
+  int64_t x1, y1, x2, y2;
+};
+
+struct Eqn {  // a*x + b*y + c = 0 with b >= 0 (map.h:216-226)
+  i128 a, b, c;
+};
+
+RJ_HD Eqn make_eqn(const Seg& s) {
+  Eqn e;
+  int64_t a = s.y1 - s.y2;
+  int64_t b = s.x2 - s.x1;
+  e.c = -(i128) s.x1 * a - (i128) s.y1 * b;
+  if (b < 0) {
+    a = -a;
+    b = -b;
+    e.c = -e.c;
+  }
+  e.a = a;
+  e.b = b;
+  return e;
+}
+
+// p.x*e.a + p.y*e.b + e.c  (lsi.h:32-33).  |p| < 2^46, |a|,|b| < 2^47, |c| < 2^94: no overflow.
+RJ_HD i128 subedge(int64_t px, int64_t py, const Eqn& e) {
+  return (i128) px * (int64_t) e.a + (i128) py * (int64_t) e.b + e.c;
+}
+
+// intersect_test(e1 = map-0 edge, e2 = map-1 edge); the operand order is part of the semantics
+// (simulation of simplicity, lsi.h:41-87).
+RJ_HD bool lsi_test(const Seg& s1, const Eqn& e1, const Seg& s2, const Eqn& e2) {
+  i128 u1 = subedge(s1.x1, s1.y1, e2);  // e1_p1 against e2
+  i128 u2 = subedge(s1.x2, s1.y2, e2);
+  if (u1 == 0) u1 = -e2.a;
+  if (u1 == 0) u1 = -e2.b;
+  if (u1 == 0) return false;
+  if (u2 == 0) u2 = -e2.a;
+  if (u2 == 0) u2 = -e2.b;
+  if (u2 == 0) return false;
+  if ((u1 > 0 && u2 > 0) || (u1 < 0 && u2 < 0)) return false;
+  i128 v1 = subedge(s2.x1, s2.y1, e1);  // e2_p1 against e1
+  i128 v2 = subedge(s2.x2, s2.y2, e1);
+  if (v1 == 0) v1 = e1.a;
+  if (v1 == 0) v1 = e1.b;
+  if (v1 == 0) return false;
+  if (v2 == 0) v2 = e1.a;
+  if (v2 == 0) v2 = e1.b;
+  if (v2 == 0) return false;
+  if ((v1 > 0 && v2 > 0) || (v1 < 0 && v2 < 0)) return false;
+  if ((s1.x1 == s2.x1 && s1.y1 == s2.y1 && s1.x2 == s2.x2 && s1.y2 == s2.y2) ||
+      (s1.x1 == s2.x2 && s1.y1 == s2.y2 && s1.x2 == s2.x1 && s1.y2 == s2.y1))
+    return false;
+  return true;
+}
+
+// ---- tcb::rational<__int128> pieces ------------------------------------------------------
+struct Rat {
+  i128 num, den;
+};
+
+RJ_HD u128 uabs128(i128 v) { return v < 0 ? (u128) 0 - (u128) v : (u128) v; }
+
+RJ_HD int ctz128(u128 v) {
+  uint64_t lo = (uint64_t) v;
+  if (lo) return __builtin_ctzll(lo);
+  return 64 + __builtin_ctzll((uint64_t) (v >> 64));
+}
+
+// |gcd(a, b)|: binary GCD on magnitudes -- same value as the reference's Euclid loop
+// (rational.h:36-43) followed by abs (rational.h:200), without 128-bit '%'.
+RJ_HD u128 gcd_mag(u128 a, u128 b) {
+  if (a == 0) return b;
+  if (b == 0) return a;
+  int sh = ctz128(a | b);
+  a >>= ctz128(a);
+  do {
+    b >>= ctz128(b);
+    if (a > b) {
+      u128 t = a;
+      a = b;
+      b = t;
+    }
+    b -= a;
+  } while (b != 0);
+  return a << sh;
+}
+
+// rational(num, denom) -> simplify()  (rational.h:87-90,198-203):
+//   g = |gcd|; num = sign(den)*num / g; den = |den| / g
+RJ_HD Rat rat_make(i128 num, i128 den) {
+  Rat r;
+  u128 g = gcd_mag(uabs128(num), uabs128(den));
+  if (g == 0) {
+    r.num = num;
+    r.den = den;
+    return r;
+  }
+  i128 sn = den < 0 ? -num : num;
+  u128 qn = uabs128(sn) / g;  // exact
+  r.num = sn < 0 ? -(i128) qn : (i128) qn;
+  r.den = (i128) (uabs128(den) / g);
+  return r;
+}
+
+RJ_HD double rat_to_double(const Rat& r) { return (double) r.num / (double) r.den; }
+
+template <typename T>
+RJ_HD T min4(T a, T b, T c, T d) {
+  T m = a < b ? a : b, n = c < d ? c : d;
+  return m < n ? m : n;
+}
+template <typename T>
+RJ_HD T max4(T a, T b, T c, T d) {
+  T m = a > b ? a : b, n = c > d ? c : d;
+  return m > n ? m : n;
+}
+
+// lsi.h:117-141: exact point of a predicate-true pair, clamped to the 4 endpoints' range.
+// int128 products wrap exactly like the reference's (two's complement).
+RJ_HD void lsi_point(const Seg& s1, const Eqn& e1, const Seg& s2, const Eqn& e2, Rat* ox, Rat* oy) {
+  u128 den = (u128) e1.a * (u128) e2.b - (u128) e2.a * (u128) e1.b;
+  u128 nx = (u128) e2.c * (u128) e1.b - (u128) e1.c * (u128) e2.b;
+  u128 ny = (u128) e2.a * (u128) e1.c - (u128) e1.a * (u128) e2.c;
+  Rat x = rat_make((i128) nx, (i128) den), y = rat_make((i128) ny, (i128) den);
+  int64_t t;
+  t = min4(s1.x1, s1.x2, s2.x1, s2.x2);
+  if (x.num < (i128) ((u128) (i128) t * (u128) x.den)) { x.num = t; x.den = 1; }
+  t = max4(s1.x1, s1.x2, s2.x1, s2.x2);
+  if ((i128) ((u128) (i128) t * (u128) x.den) < x.num) { x.num = t; x.den = 1; }
+  t = min4(s1.y1, s1.y2, s2.y1, s2.y2);
+  if (y.num < (i128) ((u128) (i128) t * (u128) y.den)) { y.num = t; y.den = 1; }
+  t = max4(s1.y1, s1.y2, s2.y1, s2.y2);
+  if ((i128) ((u128) (i128) t * (u128) y.den) < y.num) { y.num = t; y.den = 1; }
+  *ox = x;
+  *oy = y;
+}
+
+// ---- PIP ------------------------------------------------------------------------------
+// One (point, base edge) evaluation, pip.h:36-71.  Returns false when the edge is rejected
+// outright (x range / point above edge); otherwise *yy = xsect_y and *slope = (double)a/b.
+RJ_HD bool pip_eval(const Seg& s, int64_t px, int64_t py, int query_map_id, double* yy,
+                    double* slope) {
+  int64_t x_min = s.x1 < s.x2 ? s.x1 : s.x2;
+  int64_t x_max = s.x1 < s.x2 ? s.x2 : s.x1;
+  if (px < x_min || px > x_max || px == (query_map_id == 0 ? x_min : x_max)) return false;
+  Eqn e = make_eqn(s);
+  double xsect_y = (double) (-e.a * (i128) px - e.c) / (double) e.b;
+  double diff_y = (double) py - xsect_y;
+  if (diff_y == 0) diff_y = (double) (query_map_id == 0 ? -e.a : e.a);
+  if (diff_y == 0) diff_y = (double) (query_map_id == 0 ? -e.b : e.b);
+  if (diff_y > 0) return false;
+  *yy = xsect_y;
+  *slope = (double) e.a / (double) e.b;
+  return true;
+}
+
+// Does candidate (yy, slope, eid) replace best (byy, bslope, beid)?  pip.h:73-95 made a total
+// order: the reference's full ties (equal yy and slope) keep the first visited edge for
+// query map 1 and the last visited for query map 0; with edges visited in ascending eid (what
+// the oracle does) that is "smaller eid" for q==1 and "larger eid" for q==0.
+RJ_HD bool pip_better(double yy, double slope, uint32_t eid, double byy, double bslope,
+                      uint32_t beid, int query_map_id) {
+  if (yy > byy) return false;
+  if (yy < byy) return true;
+  if (beid == 0xFFFFFFFFu) return true;  // no best yet (byy == +inf == yy cannot happen, but be safe)
+  if (query_map_id) {
+    if (slope > bslope) return true;
+    if (slope < bslope) return false;
+    return eid < beid;
+  }
+  if (slope > bslope) return false;
+  if (slope < bslope) return true;
+  return eid > beid;
+}
+
+}  // namespace rj

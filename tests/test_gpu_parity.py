@@ -1,0 +1,234 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs (bit-exact: integer eid pairs, integer face ids, truncated int64 points)."""
+import numpy as np
+import pytest
+
+from rayjoin_amd import _capi, maps, ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _omap(oracle, m):
+    return oracle.Map(m.pts, m.row_index, m.left, m.right)
+
+
+@pytest.fixture(scope="module")
+def lattice_pair():
+    ctx = maps.Context([synth.lattice_map(9, 120, 11), synth.lattice_map(21, 50, 12)]).load()
+    dctx = ops.DeviceContext(ctx).LoadToDevice()
+    dctx.BuildIndex(0)
+    dctx.BuildIndex(1)
+    yield ctx, dctx
+    dctx.close()
+
+
+def _lsi(dctx, query_map_id, cap, eid_range=None):
+    lsi = ops.LSILBVH(dctx)
+    lsi.Init(cap)
+    lsi.Query(query_map_id, eid_range)
+    return lsi
+
+
+def test_lsi_equals_grid_and_brute(oracle, lattice_pair):
+    ctx, dctx = lattice_pair
+    m0, m1 = _omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1])
+    grid = oracle.lsi_grid(m0, m1, 512)
+    brute = oracle.lsi_brute(m0, m1)
+    assert len(grid) > 300 and np.array_equal(grid["eid"], brute)
+    for qm in (1, 0):  # query_exec direction (base 0) and the overlay's (base 1)
+        lsi = _lsi(dctx, qm, 4 * len(grid))
+        assert lsi.n_xsects == len(grid)
+        assert np.array_equal(lsi.get_pairs(), grid["eid"])
+        xs = lsi.get_xsects()
+        for f in ("x_num", "x_den", "y_num", "y_den", "eid", "mid_point_polygon_id"):
+            assert np.array_equal(xs[f], grid[f]), f
+
+
+def test_lsi_shards_union_equals_whole(oracle, lattice_pair):
+    ctx, dctx = lattice_pair
+    whole = _lsi(dctx, 1, 100000).get_pairs()
+    q = ctx.maps[1]
+    for nshard in (2, 3, 8):
+        parts = []
+        for c0, c1 in q.shard_chain_ranges(nshard):
+            parts.append(_lsi(dctx, 1, 100000, q.chain_range_to_eids(c0, c1)).get_pairs(sort=False))
+        got = oracle.sort_pairs(np.concatenate(parts))
+        assert np.array_equal(got, whole)
+
+
+def test_lsi_queue_overflow_reports_true_count(lattice_pair):
+    ctx, dctx = lattice_pair
+    n = _lsi(dctx, 1, 100000).n_xsects
+    lsi = ops.LSILBVH(dctx)
+    lsi.Init(7)
+    with pytest.raises(_capi.QueueOverflow) as ei:
+        lsi.Query(1)
+    assert ei.value.n_found == n and ei.value.code == _capi.RJ_E_OVERFLOW
+
+
+def test_pip_equals_grid_and_brute(oracle, lattice_pair):
+    ctx, dctx = lattice_pair
+    om = [_omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1])]
+    for qm in (1, 0):
+        base = 1 - qm
+        pts = ctx.maps[qm].pts
+        want = oracle.pip_grid(om[base], base, pts, 512)
+        assert np.array_equal(want, oracle.pip_brute(om[base], qm, pts))
+        pip = ops.PIPLBVH(dctx)
+        pip.Init(len(pts))
+        pip.Query(qm)  # the query map's own vertices, run_query.cu:346
+        got = pip.get_closest_eids()
+        assert (got != _capi.MISS_EID).sum() > 1000 and (got == _capi.MISS_EID).sum() > 0
+        assert np.array_equal(got, want)
+        assert np.array_equal(pip.get_face_ids(), om[base].face_ids(want))
+        # explicit point array + a sub-range (a shard)
+        pip.Query(qm, query_points=pts[100:1357])
+        assert np.array_equal(pip.get_closest_eids(), want[100:1357])
+        pip.Query(qm, point_range=(64, 1000))
+        assert np.array_equal(pip.get_closest_eids(), want[64:1000])
+
+
+def test_random_query_workloads(oracle, lattice_pair):
+    """GenerateLSIQueries / GeneratePIPQueries (run_query.cu:102-167): spatially incoherent."""
+    ctx, _ = lattice_pair
+    qmap = synth.generate_lsi_queries(ctx.bb, ctx.scaling, 3000, 2.0, seed=5)
+    c2 = maps.Context([ctx.planar_graphs[0], None])
+    c2.bb, c2.scaling = ctx.bb, ctx.scaling
+    c2.maps = [ctx.maps[0], qmap]
+    d2 = ops.DeviceContext(c2).LoadToDevice()
+    d2.BuildIndex(0)
+    m0 = _omap(oracle, ctx.maps[0])
+    mq = oracle.Map(qmap.pts)
+    want = oracle.lsi_brute(m0, mq)
+    assert len(want) > 20
+    lsi = _lsi(d2, 1, 10000)
+    assert np.array_equal(lsi.get_pairs(), want)
+    pts = synth.generate_pip_queries(ctx.bb, ctx.scaling, 5000, seed=6)
+    pip = ops.PIPLBVH(d2)
+    pip.Init(len(pts))
+    pip.Query(1, query_points=pts)
+    assert np.array_equal(pip.get_closest_eids(), oracle.pip_brute(m0, 1, pts))
+    d2.close()
+
+
+@pytest.mark.parametrize("seed,span,extreme", [(1, 4, False), (2, 9, False), (3, 6, True)])
+def test_adversarial_integer_lattice(oracle, seed, span, extreme):
+    """Shared endpoints, T-junctions, collinear overlaps, duplicates, axis-parallel edges, and the
+    +-2^46 corners: every simulation-of-simplicity branch, LSI and PIP, both directions."""
+    a = synth.adversarial_segments(700, span, seed, extreme)
+    b = synth.adversarial_segments(900, span, seed + 50, extreme)
+    ma, mb = maps.ScaledMap.from_segments(0, a), maps.ScaledMap.from_segments(1, b)
+    ctx = maps.Context([None, None])
+    ctx.maps = [ma, mb]
+    dctx = ops.DeviceContext(ctx).LoadToDevice()
+    dctx.BuildIndex(0)
+    dctx.BuildIndex(1)
+    o0, o1 = oracle.Map(a), oracle.Map(b)
+    want = oracle.lsi_brute(o0, o1)
+    assert len(want) > 500
+    for qm in (1, 0):
+        lsi = _lsi(dctx, qm, 4 * len(want))
+        assert np.array_equal(lsi.get_pairs(), want)
+        xs = lsi.get_xsects()
+        ref = oracle.lsi_points(o0, o1, want)
+        for f in ("x_num", "y_num", "eid"):
+            assert np.array_equal(xs[f], ref[f]), f
+    rng = np.random.default_rng(seed)
+    off = a.reshape(-1, 4)[:, :2].mean(axis=0).astype(np.int64) if extreme else 0
+    pts = rng.integers(-span - 1, span + 2, size=(3000, 2))
+    if extreme:  # sample around every corner cluster
+        corners = a[rng.integers(0, len(a), 3000)]
+        pts = corners + rng.integers(-3, 4, size=(3000, 2))
+        pts = np.clip(pts, -(1 << 46), (1 << 46) - 1)
+    for qm, ob in ((1, o0), (0, o1)):
+        pip = ops.PIPLBVH(dctx)
+        pip.Init(len(pts))
+        pip.Query(qm, query_points=pts)
+        assert np.array_equal(pip.get_closest_eids(), oracle.pip_brute(ob, qm, pts))
+    dctx.close()
+
+
+def test_adversarial_chains_face_ids(oracle):
+    pa = synth.adversarial_chains(60, 9, 12, 21)
+    pb = synth.adversarial_chains(80, 5, 12, 22)
+    ctx = maps.Context([None, None])
+    ctx.maps = [maps.ScaledMap(0, *pa), maps.ScaledMap(1, *pb)]
+    dctx = ops.DeviceContext(ctx).LoadToDevice()
+    dctx.BuildIndex(0)
+    o0, o1 = oracle.Map(*pa), oracle.Map(*pb)
+    want = oracle.lsi_brute(o0, o1)
+    assert np.array_equal(_lsi(dctx, 1, 100000).get_pairs(), want)
+    pip = ops.PIPLBVH(dctx)
+    pip.Init(len(pb[0]))
+    pip.Query(1)
+    eids = oracle.pip_brute(o0, 1, pb[0])
+    assert np.array_equal(pip.get_closest_eids(), eids)
+    assert np.array_equal(pip.get_face_ids(), o0.face_ids(eids))
+    dctx.close()
+
+
+@pytest.mark.parametrize("n0,n1", [(1, 1), (63, 65), (64, 64), (65, 4097), (0, 5), (5, 0)])
+def test_ragged_and_empty_sizes(oracle, n0, n1):
+    a = synth.adversarial_segments(n0, 30, 70 + n0)
+    b = synth.adversarial_segments(n1, 30, 90 + n1)
+    ctx = maps.Context([None, None])
+    ctx.maps = [maps.ScaledMap.from_segments(0, a), maps.ScaledMap.from_segments(1, b)]
+    dctx = ops.DeviceContext(ctx).LoadToDevice()
+    dctx.BuildIndex(0)
+    dctx.BuildIndex(1)
+    o0, o1 = oracle.Map(a), oracle.Map(b)
+    want = oracle.lsi_brute(o0, o1)
+    for qm in (1, 0):
+        assert np.array_equal(_lsi(dctx, qm, 100000).get_pairs(), want)
+    pts = np.random.default_rng(n0 + n1).integers(-31, 32, size=(257, 2))
+    pip = ops.PIPLBVH(dctx)
+    pip.Init(len(pts))
+    pip.Query(1, query_points=pts)
+    assert np.array_equal(pip.get_closest_eids(), oracle.pip_brute(o0, 1, pts))
+    pip.Query(1, query_points=pts[:0])
+    assert pip.get_closest_eids().shape == (0,)
+    dctx.close()
+
+
+def test_call_order_errors_are_reported_not_fatal():
+    h = _capi.Handle(0)
+    with pytest.raises(_capi.RayJoinError) as ei:
+        h.build_lbvh(0)
+    assert ei.value.code == _capi.RJ_E_INVALID
+    seg = synth.adversarial_segments(10, 5, 1)
+    m = maps.ScaledMap.from_segments(0, seg)
+    h.upload_map(0, m.pts, m.row_index, m.left, m.right)
+    h.upload_map(1, m.pts, m.row_index, m.left, m.right)
+    buf = h.alloc(800)
+    with pytest.raises(_capi.RayJoinError):
+        h.lsi_query(0, 1, 0, 10, 100, buf)  # index not built
+    h.build_lbvh(0)
+    with pytest.raises(_capi.RayJoinError):
+        h.lsi_query(0, 1, 0, 11, 100, buf)  # eid range out of bounds
+    with pytest.raises(_capi.RayJoinError):
+        h.upload_map(0, np.array([[1 << 46, 0], [0, 0]]), [0, 2], [0], [0])  # outside scaled range
+    with pytest.raises(_capi.RayJoinError):
+        h.upload_map(0, np.array([[0, 0]]), [0, 1], [0], [0])  # 1-point chain (planar_graph.h:71)
+    h.close()
+
+
+def test_medium_maps_against_grid_oracle(oracle):
+    """~0.2 M x 0.55 M edges: the CPU grid finishes in seconds; brute force no longer does."""
+    ctx = maps.Context([synth.lattice_map(24, 350, 31), synth.lattice_map(130, 16, 32)]).load()
+    dctx = ops.DeviceContext(ctx).LoadToDevice()
+    dctx.BuildIndex(0)
+    m0, m1 = _omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1])
+    grid = oracle.lsi_grid(m0, m1, 2048)
+    lsi = _lsi(dctx, 1, 4 * len(grid) + 1000)
+    assert lsi.n_xsects == len(grid) > 3000
+    assert np.array_equal(lsi.get_pairs(), grid["eid"])
+    xs = lsi.get_xsects()
+    assert np.array_equal(xs["x_num"], grid["x_num"]) and np.array_equal(xs["y_num"], grid["y_num"])
+    pts = ctx.maps[1].pts
+    pip = ops.PIPLBVH(dctx)
+    pip.Init(len(pts))
+    pip.Query(1)
+    want = oracle.pip_grid(m0, 0, pts, 2048)
+    assert np.array_equal(pip.get_closest_eids(), want)
+    assert np.array_equal(pip.get_face_ids(), m0.face_ids(want))
+    dctx.close()
