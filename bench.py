@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""bench.py -- LSI + PIP query throughput of the MI355X-native path (BASELINE.json metric).
+
+A step = one LSI Query (all query-map segments against the indexed base map: queue clear,
+kernel, count read-back, sync -- exactly what the reference times, src/run_query.cu:297-303)
+followed by one PIP Query (every vertex of the query map, src/run_query.cu:346,441-457).
+Workload (N=1): BASELINE.json configs[1], USCounty (base, 7.1 M segments) |><| BlockGroup
+(query, 28.8 M segments), as synthetic stand-ins of those sizes (the real files are
+not obtainable).  Inputs are resident in HBM before the timed region.  Index build is timed
+separately and reported, never part of `value`.
+
+N>1 (torchrun, one rank per GPU): the query map is sharded by contiguous chain ranges balanced
+by edge count, the base map + LBVH are replicated, and each step ends with an RCCL all-gather
+of the per-rank result queues (LSI pairs, PIP eids).  Total work is fixed: "strong" scaling.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)    # the reference's -repeat=5
+    ap.add_argument("--warmup", type=int, default=5)   # the reference's -warmup=5
+    ap.add_argument("--base", default="USCounty")
+    ap.add_argument("--query", default="BlockGroup")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink both stand-ins (debug only)")
+    ap.add_argument("--xsect-factor", type=float, default=0.1, help="queue capacity factor (expr/env.sh)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scale", type=float, default=1.0)
+    ap.add_argument("--check", action="store_true", help="size-independent result checks after timing")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, ctx):
+    """CPU restatement of -mode=grid (the oracle, kind 'port') timed beside the GPU numbers, on
+    all host cores.  Default sample = the whole workload (about 10-20 s of query work on 16
+    cores); --cpu-scale < 1 regenerates both stand-ins at that fraction of the lattice resolution
+    (same per-segment geometry, ~scale^2 of the segments).  Query time only, like the GPU side."""
+    from oracle import rjoracle as O
+    from rayjoin_amd import maps, synth
+    if args.cpu_scale != 1.0:
+        g0 = synth.standin(args.base, args.cpu_scale * args.scale)
+        g1 = synth.standin(args.query, args.cpu_scale * args.scale)
+        ctx = maps.Context([g0, g1]).load()
+    m0 = O.Map(ctx.maps[0].pts, ctx.maps[0].row_index, ctx.maps[0].left, ctx.maps[0].right)
+    m1 = O.Map(ctx.maps[1].pts, ctx.maps[1].row_index, ctx.maps[1].left, ctx.maps[1].right)
+    L = O.lib()
+    gsize = 2048  # src/flags.cc:6 default
+    t0 = time.perf_counter()
+    grid = L.rjo_grid_build(m0.h, m1.h, gsize)
+    t_build = time.perf_counter() - t0
+    cap = int(0.5 * (m0.ne + m1.ne)) + 1024
+    out = np.zeros(cap, dtype=O.XSECT_DTYPE)
+    t0 = time.perf_counter()
+    n = L.rjo_lsi_grid(m0.h, m1.h, grid, out.ctypes.data, cap)
+    t_lsi = time.perf_counter() - t0
+    L.rjo_grid_free(grid)
+    grid = L.rjo_grid_build(m0.h, None, gsize)
+    pts = ctx.maps[1].pts
+    res = np.empty(pts.shape[0], dtype=np.uint32)
+    t0 = time.perf_counter()
+    L.rjo_pip_grid(m0.h, 0, grid, pts, pts.shape[0], res)
+    t_pip = time.perf_counter() - t0
+    L.rjo_grid_free(grid)
+    return {
+        "value": round(m1.ne / (t_lsi + t_pip) / 1e6, 4), "unit": "M query segments/s (LSI+PIP)",
+        "cores": O.num_threads(), "kind": "port",
+        "sample": "%s x %s stand-ins at %.3g of the lattice resolution (1 = the whole workload): %d base / %d query segments, "
+                  "%d intersections; grid_size %d; lsi %.1f ms, pip %.1f ms (grid build %.1f ms not counted)"
+                  % (args.base, args.query, args.cpu_scale * args.scale, m0.ne, m1.ne, n, gsize,
+                     t_lsi * 1e3, t_pip * 1e3, t_build * 1e3),
+        "lsi_msegs_per_s": round(m1.ne / t_lsi / 1e6, 4),
+        "pip_mpoints_per_s": round(pts.shape[0] / t_pip / 1e6, 4),
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from rayjoin_amd import _capi, maps, synth
+
+    # ---- synthetic workload (identical on every rank: seeded) -------------------------------
+    t0 = time.perf_counter()
+    g0 = synth.standin(args.base, args.scale)
+    g1 = synth.standin(args.query, args.scale)
+    ctx = maps.Context([g0, g1]).load()
+    base, query = ctx.maps[0], ctx.maps[1]
+    t_gen = time.perf_counter() - t0
+    n_r, n_s, n_p = base.n_edges, query.n_edges, query.n_points
+
+    h = _capi.Handle(local_rank)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    t0 = time.perf_counter()
+    h.upload_map(0, base.pts, base.row_index, base.left, base.right)
+    h.upload_map(1, query.pts, query.row_index, query.left, query.right)
+    t_upload = time.perf_counter() - t0
+    h.build_lbvh(0)
+    h.build_lbvh(0)  # second build = steady-state allocator
+    build_ms = h.last_ms(_capi.RJ_T_BUILD)
+
+    # ---- shard the query map by chain range -------------------------------------
+    c0, c1 = query.shard_chain_ranges(world)[rank]
+    e0, e1 = query.chain_range_to_eids(c0, c1)
+    p0, p1 = int(query.row_index[c0]), int(query.row_index[c1])
+    cap = int(args.xsect_factor * (n_r + n_s))  # run_query.cu:226-228
+    pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    closest = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
+    faces = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
+    if world > 1:
+        max_pts = max(int(query.row_index[b]) - int(query.row_index[a]) for a, b in query.shard_chain_ranges(world))
+        cnt_all = torch.zeros(world, dtype=torch.int64, device=dev)
+        cnt_me = torch.zeros(1, dtype=torch.int64, device=dev)
+        pairs_all = torch.empty(world * cap * 2, dtype=torch.int32, device=dev)
+        ids_pad = torch.empty(max_pts, dtype=torch.int32, device=dev)
+        ids_all = torch.empty((world, max_pts), dtype=torch.int32, device=dev)
+
+    lsi_ms, pip_ms = [], []
+    state = {}
+
+    def step(record):
+        n = h.lsi_query(0, 1, e0, e1, cap, pairs)
+        if record:
+            lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
+        if world > 1:  # all-gatherv of the intersection queues: counts, then the used prefix, padded
+            cnt_me[0] = n
+            dist.all_gather_into_tensor(cnt_all, cnt_me)
+            gmax = int(cnt_all.max().item())
+            recv = pairs_all[:world * gmax * 2].view(world, gmax, 2)
+            dist.all_gather_into_tensor(recv, pairs[:gmax])
+            state["pairs_all"], state["cnt_all"] = recv, cnt_all
+        h.pip_query(0, 1, None, p0, p1 - p0, closest, faces)
+        if record:
+            pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
+        if world > 1:
+            ids_pad[:p1 - p0] = closest[:p1 - p0]
+            dist.all_gather_into_tensor(ids_all, ids_pad)
+            state["ids_all"] = ids_all
+        state["n"] = n
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([state["n"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        n_x = int(tot.item())
+    else:
+        n_x = state["n"]
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # phase split (synchronous calls, wall clock), one extra untimed pass
+    t0 = time.perf_counter(); h.lsi_query(0, 1, e0, e1, cap, pairs); t_lsi_wall = time.perf_counter() - t0
+    t0 = time.perf_counter(); h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); t_pip_wall = time.perf_counter() - t0
+
+    checks = None
+    if args.check and rank == 0 and world == 1:
+        checks = run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1)
+
+    if rank == 0:
+        lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms))
+        # ALGORITHMIC bytes: every input element once, every output once
+        n_s_loc, n_p_loc = e1 - e0, p1 - p0
+        b_lsi = 32 * n_s_loc + 32 * n_r + 8 * state["n"]
+        b_pip = 16 * n_p_loc + 32 * n_r + 4 * n_p_loc + 4 * n_p_loc  # + face ids
+        traffic = {}
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp) and world == 1 and args.scale == 1.0:
+            traffic = json.load(open(tp))
+        roof = {}
+        for name, b, ms, kern in (("lsi", b_lsi, lsi_k, "k_lsi"), ("pip", b_pip, pip_k, "k_pip")):
+            ach = b / (ms * 1e-3) / 1e9
+            roof[name] = {"bound": "hbm", "kernel": kern, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(kern),
+                          "algorithmic_bytes": b, "kernel_ms": round(ms, 4)}
+        dom = "lsi" if lsi_k >= pip_k else "pip"
+        out = {
+            "metric": "LSI+PIP query throughput, %s |><| %s" % (args.base, args.query),
+            "value": round(n_s / (ms_per_step * 1e-3) / 1e6, 3), "unit": "M query segments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "int128+f64", "data": "synthetic",
+            "config": {"workload": "%s(base, %d segs) |><| %s(query, %d segs, %d points), -query=lsi then -query=pip, "
+                                   "-mode=lbvh (software LBVH)" % (args.base, n_r, args.query, n_s, n_p),
+                       "sharding": "query map by chain range x%d, base+LBVH replicated, RCCL all-gather of result queues" % world
+                                   if world > 1 else "single GPU",
+                       "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale},
+            "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
+            "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
+            "pip_mpoints_per_s": round(n_p / max(t_pip_wall, 1e-9) / 1e6, 2) if world == 1 else None,
+            "intersections": n_x, "build_index_ms": round(build_ms, 3),
+            "host_ms": {"generate": round(t_gen * 1e3, 1), "upload_and_segment_build": round(t_upload * 1e3, 1)},
+            "roofline": roof[dom], "roofline_other": roof["pip" if dom == "lsi" else "lsi"],
+        }
+        if checks is not None:
+            out["checks"] = checks
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, ctx)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    h.close()
+
+
+def run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1):
+    """Size-independent properties at full size (no oracle can run here in seconds):
+    role symmetry, shard additivity, sortedness/uniqueness, permutation invariance of PIP."""
+    from rayjoin_amd import _capi
+    res = {}
+    h.sort_pairs(pairs, n_x)
+    a = pairs[:n_x].to(torch.int64)
+    key = (a[:, 0] & 0xFFFFFFFF) * (1 << 32) + (a[:, 1] & 0xFFFFFFFF)
+    res["sorted_unique"] = bool((key[1:] > key[:-1]).all().item()) if n_x > 1 else True
+    # role symmetry: index the query map instead; the pair SET must be identical because the
+    # predicate is always evaluated as (map-0 edge, map-1 edge)
+    h.build_lbvh(1)
+    n_r = h.map_num_edges(0)
+    p2 = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    n2 = h.lsi_query(1, 0, 0, n_r, cap, p2)
+    h.sort_pairs(p2, n2)
+    res["role_symmetry"] = bool(n2 == n_x and torch.equal(p2[:n2], pairs[:n_x]))
+    # shard additivity
+    mid = (e0 + e1) // 2
+    pa = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    na = h.lsi_query(0, 1, e0, mid, cap, pa)
+    pb = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+    nb = h.lsi_query(0, 1, mid, e1, cap, pb)
+    both = torch.cat([pa[:na], pb[:nb]])
+    h.sort_pairs(both, na + nb)
+    res["shard_additivity"] = bool(na + nb == n_x and torch.equal(both, pairs[:n_x]))
+    # PIP permutation invariance on a 1 M-point sample
+    npts = min(1 << 20, query.n_points)
+    pts = torch.from_numpy(query.pts[:npts]).to(dev)
+    perm = torch.randperm(npts, device=dev)
+    c1 = torch.empty(npts, dtype=torch.int32, device=dev)
+    c2 = torch.empty(npts, dtype=torch.int32, device=dev)
+    h.pip_query(0, 1, pts, 0, npts, c1, None)
+    h.pip_query(0, 1, pts[perm].contiguous(), 0, npts, c2, None)
+    res["pip_permutation_invariance"] = bool(torch.equal(c1[perm], c2) and torch.equal(c1, closest[:npts]))
+    return res
+
+
+if __name__ == "__main__":
+    main()
