@@ -133,8 +133,10 @@ int rj_last_ms(rj_handle h, int which, float* ms);
 /* traversal statistics of the last LSI/PIP query (diagnostic; mirrors the reference's
  * "Total tests"/"Visited nodes" debug counters, src/app/lsi_lbvh.h:37-42,93-94):
  * stats[0] = leaf blocks visited, [1] = candidate pairs tested exactly, [2] = nodes expanded,
- * [3] = box tests in the leaf loop.  Collected only after rj_set_option(h,"stats",1). */
-int rj_last_stats(rj_handle h, uint64_t stats[4]);
+ * [3] = box tests in the leaf loop; [4..9] = summed per-wave cycle stamps of the instrumented
+ * build (total, node expansion, leaf loop, dense predicate phase, merge rounds, max wave total).
+ * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
+int rj_last_stats(rj_handle h, uint64_t stats[16]);
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 
 /* ---- device memory helpers (for hosts without their own allocator) -------------------- */

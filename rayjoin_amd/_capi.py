@@ -234,6 +234,8 @@ class Handle:
         return ms.value
 
     def last_stats(self):
-        s = (_u64 * 4)()
+        s = (_u64 * 16)()
         self._check(self.L.rj_last_stats(self.h, s))
-        return dict(leaf_blocks=s[0], exact_tests=s[1], nodes_expanded=s[2], leaf_box_tests=s[3])
+        return dict(leaf_blocks=s[0], exact_tests=s[1], nodes_expanded=s[2], leaf_box_tests=s[3],
+                    cyc_total=s[4], cyc_node=s[5], cyc_leaf=s[6], cyc_drain=s[7], merge_rounds=s[8],
+                    cyc_max_wave=s[9])

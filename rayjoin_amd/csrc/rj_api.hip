@@ -55,7 +55,7 @@ struct rj_handle_s {
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
   int max_blocks = 256 * 8;  // 256 CUs x 8 blocks of 256 threads
-  uint64_t last_stats[4] = {0, 0, 0, 0};
+  uint64_t last_stats[16] = {0};
   std::string err;
 };
 
@@ -143,8 +143,8 @@ int rj_create(int device_id, rj_handle* out) {
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RJ_E_HIP; }
   h->stream = h->own_stream;
   bool ok = hipMalloc((void**) &h->d_counter, 8) == hipSuccess &&
-            hipMalloc((void**) &h->d_stats, 32) == hipSuccess &&
-            hipHostMalloc((void**) &h->h_pinned, 64) == hipSuccess;
+            hipMalloc((void**) &h->d_stats, 128) == hipSuccess &&
+            hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess;
   for (int t = 0; ok && t < kNumTimers; t++)
     ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
   if (!ok) { delete h; return RJ_E_HIP; }
@@ -331,7 +331,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query: null output");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear (queue.h:125-129)
-  if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 32, h->stream));
+  if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   LsiArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.qseg = h->map[query_map_id].seg;
@@ -356,10 +356,10 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   RJ_CHECK_H(h);
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter, 8, hipMemcpyDeviceToHost, h->stream));
-  if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 32, hipMemcpyDeviceToHost, h->stream));
+  if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   uint64_t n = h->h_pinned[0];
-  if (h->stats_on) for (int i = 0; i < 4; i++) h->last_stats[i] = h->h_pinned[1 + i];
+  if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
   if (n_found) *n_found = n;
   if (n > capacity)
     return fail(h, RJ_E_OVERFLOW, "intersection queue overflow: %llu found, capacity %llu",
@@ -424,7 +424,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     pts = q.pts + 2 * pt_begin;
   }
   if (int r = set_device(h)) return r;
-  if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 32, h->stream));
+  if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.base = map_view(h->map[base_map_id]);
@@ -442,9 +442,9 @@ int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* 
                  uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev) {
   RJ_CHECK_H(h);
   if (int r = rj_pip_query_async(h, base_map_id, query_map_id, pts_dev, pt_begin, n, closest_eid_dev, face_id_dev)) return r;
-  if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 32, hipMemcpyDeviceToHost, h->stream));
+  if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
-  if (h->stats_on) for (int i = 0; i < 4; i++) h->last_stats[i] = h->h_pinned[1 + i];
+  if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
   return RJ_OK;
 }
 
@@ -458,10 +458,10 @@ int rj_last_ms(rj_handle h, int which, float* ms) {
   return RJ_OK;
 }
 
-int rj_last_stats(rj_handle h, uint64_t stats[4]) {
+int rj_last_stats(rj_handle h, uint64_t stats[16]) {
   RJ_CHECK_H(h);
   if (!stats) return fail(h, RJ_E_INVALID, "null stats");
-  for (int i = 0; i < 4; i++) stats[i] = h->last_stats[i];
+  for (int i = 0; i < 16; i++) stats[i] = h->last_stats[i];
   return RJ_OK;
 }
 

@@ -176,8 +176,11 @@ __global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
   const DeviceBvh& T = A.bvh;
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
+  long long tk_node = 0, tk_leaf = 0, tk_head = 0;  // STATS: cycle stamps
+  const long long tk_begin = STATS ? clock64() : 0;
 
   for (uint64_t g = (uint64_t) blockIdx.x * 4 + wib; g < ngroups; g += nwaves) {
+    const long long tkg = STATS ? clock64() : 0;
     const uint64_t q = A.qbeg + g * 64 + lane;
     const bool valid = q < A.qend;
     int32_t qx0 = kEmptyMin, qy0 = kEmptyMin, qx1 = kEmptyMax, qy1 = kEmptyMax;
@@ -191,28 +194,43 @@ __global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
     const int32_t gx0 = wave_min(qx0), gy0 = wave_min(qy0);
     const int32_t gx1 = wave_max(qx1), gy1 = wave_max(qy1);
 
+    // A child is pushed only if SOME lane's own query box overlaps it: the union box is just
+    // a cheap first filter.  The wave therefore visits exactly the union of the nodes its 64
+    // queries need, whatever the spatial coherence of the group.
+    auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
+      uint64_t keep = 0;
+      while (um) {
+        const int c = __builtin_ctzll(um);
+        um &= um - 1;
+        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
+        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
+        if (__ballot(qx0 <= cx1 && cx0 <= qx1 && qy0 <= cy1 && cy0 <= qy1)) keep |= 1ull << c;
+      }
+      return keep;
+    };
     int sp = 0;
     {  // top level: <= 64 nodes, one per lane
       QBox b = T.lvl[T.top][lane];
-      bool hit = overlap(b, gx0, gy0, gx1, gy1);
-      uint64_t m = __ballot(hit);
-      if (hit) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
+      uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
       sp = __popcll(m);
       wave_lds_fence();
     }
+    if (STATS) tk_head += clock64() - tkg;
     while (sp > 0) {
       uint32_t e = __builtin_amdgcn_readfirstlane(L.stack[sp - 1]);
       --sp;
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
+      const long long tk0 = STATS ? clock64() : 0;
       if (lvl > 1) {
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
-        bool hit = overlap(b, gx0, gy0, gx1, gy1);
-        uint64_t m = __ballot(hit);
-        if (hit) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
+        uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
         sp += __popcll(m);
         if (STATS) st_nodes++;
         wave_lds_fence();
+        if (STATS) tk_node += clock64() - tk0;
       } else {
         // leaf block: 64 base segments, one box per lane
         const uint32_t slot0 = idx * 64;
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
             if (np >= 64) lsi_drain<STATS>(L, np, nh, 64, A, lane, st_tests);
           }
         }
+        if (STATS) tk_leaf += clock64() - tk0;
       }
     }
   }
@@ -242,10 +261,16 @@ __global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
   if (nh >= 64) lsi_flush_hits<STATS>(L, nh, 64, A, lane);
   if (nh > 0) lsi_flush_hits<STATS>(L, nh, nh, A, lane);
   if (STATS && lane == 0 && A.stats) {
+    const long long tk_total = clock64() - tk_begin;
     atomicAdd(&A.stats[0], st_leaf);
     atomicAdd(&A.stats[1], st_tests);
     atomicAdd(&A.stats[2], st_nodes);
     atomicAdd(&A.stats[3], st_box);
+    atomicAdd(&A.stats[4], (unsigned long long) tk_total);
+    atomicAdd(&A.stats[5], (unsigned long long) tk_node);
+    atomicAdd(&A.stats[6], (unsigned long long) tk_leaf);  // includes the dense predicate phase
+    atomicAdd(&A.stats[7], (unsigned long long) tk_head);  // group load + union box + top level
+    atomicMax(&A.stats[9], (unsigned long long) tk_total);
   }
 }
 
@@ -316,6 +341,8 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
+  long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_total = 0, tk_rounds = 0;  // STATS: cycle stamps
+  const long long tk_begin = STATS ? clock64() : 0;
 
   for (uint64_t g = (uint64_t) blockIdx.x * 4 + wib; g < ngroups; g += nwaves) {
     const uint64_t ip = g * 64 + lane;
@@ -338,6 +365,7 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
 
     auto drain = [&](int n) {
       // evaluate the top n (<= 64) candidates densely, then deliver results to their query lane
+      const long long tk0 = STATS ? clock64() : 0;
       bool pending = false;
       int ql = 0;
       double yy = 0, slope = 0;
@@ -358,6 +386,7 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
       np -= n;
       if (STATS) st_tests += n;
       while (__ballot(pending)) {
+        if (STATS) tk_rounds++;
         if (pending) L.mailbox[ql] = (uint32_t) lane;  // one winner per query lane
         wave_lds_fence();
         const bool win = pending && L.mailbox[ql] == (uint32_t) lane;
@@ -380,16 +409,29 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
       }
       if (valid && best_eid != 0xFFFFFFFFu) lane_qbest = quant_best(best_yy);
       gbest = wave_max(lane_qbest);
+      if (STATS) tk_drain += clock64() - tk0;
     };
 
+    // push-time per-lane culling (see k_lsi): a child survives only if SOME lane's upward ray
+    // can still hit it given that lane's current best
+    auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
+      uint64_t keep = 0;
+      while (um) {
+        const int c = __builtin_ctzll(um);
+        um &= um - 1;
+        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
+        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
+        if (__ballot(cx0 <= qx && qx <= cx1 && cy1 >= qy - 1 && cy0 <= lane_qbest)) keep |= 1ull << c;
+      }
+      return keep;
+    };
     int sp = 0;
     {
       QBox b = T.lvl[T.top][lane];
-      bool hit = b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1;
-      uint64_t m = __ballot(hit);
+      uint64_t m = refine(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
       const int cnt = __popcll(m);
       // reversed so that lane 0's child (lowest Morton = lowest y half) pops first
-      if (hit) L.stack[cnt - 1 - rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
+      if ((m >> lane) & 1) L.stack[cnt - 1 - rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
       sp = cnt;
       wave_lds_fence();
     }
@@ -399,15 +441,18 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
       if (lvl > 1) {
+        const long long tk0 = STATS ? clock64() : 0;
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
-        bool hit = b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest;
-        uint64_t m = __ballot(hit);
+        uint64_t m = refine(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
         const int cnt = __popcll(m);
-        if (hit) L.stack[sp + cnt - 1 - rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
+        if ((m >> lane) & 1) L.stack[sp + cnt - 1 - rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
         sp += cnt;
         if (STATS) st_nodes++;
         wave_lds_fence();
+        if (STATS) tk_node += clock64() - tk0;
       } else {
+        const long long tk0 = STATS ? clock64() : 0;
+        const long long tkd0 = tk_drain;
         const uint32_t slot0 = idx * 64;
         QBox bb = T.box0[(uint64_t) slot0 + lane];
         uint64_t bm = __ballot(bb.x0 <= gx1 && gx0 <= bb.x1 && bb.y1 >= gy0 - 1 && bb.y0 <= gbest);
@@ -427,6 +472,7 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
             if (np >= 64) drain(64);
           }
         }
+        if (STATS) tk_leaf += (clock64() - tk0) - (tk_drain - tkd0);
       }
     }
     if (np > 0) drain(np);
@@ -444,10 +490,17 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
     }
   }
   if (STATS && lane == 0 && A.stats) {
+    tk_total = clock64() - tk_begin;
     atomicAdd(&A.stats[0], st_leaf);
     atomicAdd(&A.stats[1], st_tests);
     atomicAdd(&A.stats[2], st_nodes);
     atomicAdd(&A.stats[3], st_box);
+    atomicAdd(&A.stats[4], (unsigned long long) tk_total);
+    atomicAdd(&A.stats[5], (unsigned long long) tk_node);
+    atomicAdd(&A.stats[6], (unsigned long long) tk_leaf);
+    atomicAdd(&A.stats[7], (unsigned long long) tk_drain);
+    atomicAdd(&A.stats[8], (unsigned long long) tk_rounds);
+    atomicMax(&A.stats[9], (unsigned long long) tk_total);
   }
 }
 
