@@ -60,7 +60,9 @@ typedef struct {
 /* replaces: Context() + Stream (src/context.h:31-74,119; src/util/stream.h:13-27) */
 int rj_create(int device_id, rj_handle* out);
 int rj_destroy(rj_handle h);
-/* run all work of this handle on a caller-owned hipStream_t (NULL = the handle's own stream) */
+/* run all work of this handle on a caller-owned hipStream_t; NULL is HIP's null (legacy default)
+ * stream.  A new handle uses a private non-blocking stream (rj_set_option(h,"own_stream",1)
+ * returns to it). */
 int rj_set_stream(rj_handle h, void* hip_stream);
 int rj_sync(rj_handle h);
 const char* rj_last_error_string(rj_handle h);

@@ -166,7 +166,7 @@ int rj_destroy(rj_handle h) {
 
 int rj_set_stream(rj_handle h, void* s) {
   RJ_CHECK_H(h);
-  h->stream = s ? (hipStream_t) s : h->own_stream;
+  h->stream = (hipStream_t) s;  // NULL is HIP's null (legacy default) stream, e.g. torch's default
   return RJ_OK;
 }
 
@@ -183,6 +183,7 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   RJ_CHECK_H(h);
   if (!name) return fail(h, RJ_E_INVALID, "null option name");
   if (!strcmp(name, "stats")) { h->stats_on = value != 0; return RJ_OK; }
+  if (!strcmp(name, "own_stream")) { h->stream = h->own_stream; return RJ_OK; }
   if (!strcmp(name, "max_blocks")) {
     if (value < 1 || value > 65536) return fail(h, RJ_E_INVALID, "max_blocks out of range");
     h->max_blocks = (int) value;
