@@ -472,6 +472,9 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
             if (np >= 64) drain(64);
           }
         }
+        // drain eagerly: the sooner a lane knows its best, the more of the column above it is
+        // pruned (a partial drain costs far less than one more leaf block)
+        if (np > 0) drain(np);
         if (STATS) tk_leaf += (clock64() - tk0) - (tk_drain - tkd0);
       }
     }
