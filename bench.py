@@ -125,20 +125,16 @@ def main():
     build_ms = h.last_ms(_capi.RJ_T_BUILD)
 
     # ---- shard the query map by chain range -------------------------------------
-    c0, c1 = query.shard_chain_ranges(world)[rank]
-    e0, e1 = query.chain_range_to_eids(c0, c1)
-    p0, p1 = int(query.row_index[c0]), int(query.row_index[c1])
+    from rayjoin_amd import dist as rjd
+    sh = rjd.shard_of(query, world, rank)
+    (e0, e1), (p0, p1) = sh["eids"], sh["points"]
     cap = int(args.xsect_factor * (n_r + n_s))  # run_query.cu:226-228
     pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     closest = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
     faces = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
     if world > 1:
-        max_pts = max(int(query.row_index[b]) - int(query.row_index[a]) for a, b in query.shard_chain_ranges(world))
-        cnt_all = torch.zeros(world, dtype=torch.int64, device=dev)
-        cnt_me = torch.zeros(1, dtype=torch.int64, device=dev)
-        pairs_all = torch.empty(world * cap * 2, dtype=torch.int32, device=dev)
-        ids_pad = torch.empty(max_pts, dtype=torch.int32, device=dev)
-        ids_all = torch.empty((world, max_pts), dtype=torch.int32, device=dev)
+        max_pts = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
+        scratch = torch.empty(world * cap * 2, dtype=torch.int32, device=dev)
 
     lsi_ms, pip_ms = [], []
     state = {}
@@ -147,20 +143,13 @@ def main():
         n = h.lsi_query(0, 1, e0, e1, cap, pairs)
         if record:
             lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
-        if world > 1:  # all-gatherv of the intersection queues: counts, then the used prefix, padded
-            cnt_me[0] = n
-            dist.all_gather_into_tensor(cnt_all, cnt_me)
-            gmax = int(cnt_all.max().item())
-            recv = pairs_all[:world * gmax * 2].view(world, gmax, 2)
-            dist.all_gather_into_tensor(recv, pairs[:gmax])
-            state["pairs_all"], state["cnt_all"] = recv, cnt_all
+        if world > 1:  # RCCL all-gather-v of the intersection queues
+            state["pairs_all"], state["cnt_all"] = rjd.allgather_pairs(pairs, n, scratch)
         h.pip_query(0, 1, None, p0, p1 - p0, closest, faces)
         if record:
             pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
-        if world > 1:
-            ids_pad[:p1 - p0] = closest[:p1 - p0]
-            dist.all_gather_into_tensor(ids_all, ids_pad)
-            state["ids_all"] = ids_all
+        if world > 1:  # RCCL all-gather of the PIP result queues (contiguous point shards)
+            state["ids_all"] = rjd.allgather_point_results(closest, p1 - p0, max_pts)
         state["n"] = n
 
     def barrier():

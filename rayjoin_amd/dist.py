@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of the query map and gathering of result queues.
+
+The reference is single-GPU (no NCCL/MPI anywhere); this is new design.  Each query segment /
+point is independent against a read-only base map + LBVH, so the query map is split into
+contiguous CHAIN ranges balanced by edge count (a chain range is a contiguous eid range and a
+contiguous point range, because eid = p_idx - ichain, src/map/map.h:200-203), the base map and
+its LBVH are replicated, and the only exchange step is an all-gather(v) of the result queues:
+one all-gather of per-rank counts + one padded all-gather of the used prefix.  On GPUs the
+backend is "nccl" (= RCCL over xGMI); the same code runs on "gloo" for CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_of(query_map, world, rank):
+    """-> dict(chains=(c0,c1), eids=(e0,e1), points=(p0,p1)) of this rank's shard."""
+    c0, c1 = query_map.shard_chain_ranges(world)[rank]
+    e0, e1 = query_map.chain_range_to_eids(c0, c1)
+    return dict(chains=(c0, c1), eids=(e0, e1),
+                points=(int(query_map.row_index[c0]), int(query_map.row_index[c1])))
+
+
+def allgather_counts(n, device):
+    world = dist.get_world_size()
+    me = torch.tensor([int(n)], dtype=torch.int64, device=device)
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, me)
+    return out
+
+
+def allgather_pairs(pairs, n, scratch=None):
+    """All-gather-v of (eid0, eid1) pair queues.  pairs: int32[cap,2] tensor whose first n rows
+    are valid on this rank.  Returns (gathered int32[total,2] in rank order, counts int64[world]).
+    `scratch`: optional preallocated flat int32 buffer of >= world*max_count*2 elements."""
+    world = dist.get_world_size()
+    counts = allgather_counts(n, pairs.device)
+    cl = counts.tolist()
+    gmax = max(cl) if cl else 0
+    if gmax == 0:
+        return pairs[:0], counts
+    if pairs.shape[0] < gmax:  # only possible if some rank overflowed its queue
+        raise ValueError("local queue smaller than the largest shard result")
+    if scratch is not None and scratch.numel() >= world * gmax * 2:
+        flat = scratch[:world * gmax * 2]
+    else:
+        flat = torch.empty(world * gmax * 2, dtype=pairs.dtype, device=pairs.device)
+    dist.all_gather_into_tensor(flat, pairs[:gmax].reshape(-1))  # flat in, flat out: nccl and gloo
+    recv = flat.view(world, gmax, 2)
+    out = torch.cat([recv[r, :cl[r]] for r in range(world)], dim=0)
+    return out, counts
+
+
+def allgather_point_results(ids, n, max_n):
+    """All-gather of per-point results (closest eids / face ids) of contiguous point shards;
+    shards are contiguous point ranges in rank order, so concatenation restores point order.
+    ids: int32[>=n] on this rank, max_n: the largest shard size (same on every rank)."""
+    world = dist.get_world_size()
+    pad = torch.zeros(max_n, dtype=ids.dtype, device=ids.device)
+    pad[:n] = ids[:n]
+    flat = torch.empty(world * max_n, dtype=ids.dtype, device=ids.device)
+    dist.all_gather_into_tensor(flat, pad)
+    recv = flat.view(world, max_n)
+    counts = allgather_counts(n, ids.device).tolist()
+    return torch.cat([recv[r, :counts[r]] for r in range(world)], dim=0)

@@ -1,0 +1,208 @@
+// query_exec -- RayJoin's LSI / PIP benchmark driver (src/query.cc, src/run_query.cu) with the
+// MI355X-native -mode=lbvh path behind it.  Same flags, same phases, same stderr timing format.
+//   -mode=lbvh : software LBVH in hand-written HIP (this repository)
+//   -mode=rt   : rejected -- gfx950 has no ray-tracing units (the reference's OptiX path)
+//   -mode=grid : rejected here -- the uniform-grid algorithm exists in this repository only as
+//                the CPU parity oracle (oracle/, test infrastructure), never as a product path
+#include <cstdio>
+#include <iostream>
+#include <random>
+
+#include "context.h"
+#include "flags.h"
+#include "lsi_pip.h"
+#include "timer.h"
+
+using namespace rayjoin;
+
+namespace {
+
+void Usage(const char* argv0) {
+  std::cerr << "Usage: " << argv0 << " -poly1 <base.cdb> [-poly2 <query.cdb>] -query lsi|pip -mode lbvh\n"
+            << "  [-serialize <dir>] [-xsect_factor 0.2] [-warmup 5] [-repeat 5] [-seed N] [-gen_n 10000]\n"
+            << "  [-gen_t 0.1] [-output <pairs.txt>] [-device 0] [-v 1]\n";
+}
+
+// GenerateLSIQueries (run_query.cu:102-144)
+std::shared_ptr<HostMap> GenerateLSIQueries(const Flags& f, Context& ctx) {
+  auto bb = ctx.get_bounding_box();
+  auto& sc = ctx.get_scaling();
+  std::random_device rd;
+  std::mt19937 gen(f.seed == 0 ? rd() : f.seed);
+  std::uniform_real_distribution<> dx(bb.min_x, bb.max_x), dy(bb.min_y, bb.max_y), dt(0, f.gen_t);
+  auto m = std::make_shared<HostMap>();
+  size_t ne = f.gen_n;
+  for (size_t i = 0; i < ne; i++) {
+    double x1 = dx(gen), y1 = dy(gen), x2 = dx(gen), y2 = dy(gen);
+    double len = std::sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1));
+    double ux = (x2 - x1) / len, uy = (y2 - y1) / len, t = dt(gen);
+    m->xy.push_back(sc.ScaleX(x1)); m->xy.push_back(sc.ScaleY(y1));
+    m->xy.push_back(sc.ScaleX(x1 + t * ux)); m->xy.push_back(sc.ScaleY(y1 + t * uy));
+    m->row_index.push_back((uint32_t) (2 * i));
+    m->left.push_back(0); m->right.push_back(0);
+  }
+  m->row_index.push_back((uint32_t) (2 * ne));
+  return m;
+}
+
+// GeneratePIPQueries (run_query.cu:147-167)
+std::vector<int64_t> GeneratePIPQueries(const Flags& f, Context& ctx) {
+  auto bb = ctx.get_bounding_box();
+  auto& sc = ctx.get_scaling();
+  std::random_device rd;
+  std::mt19937 gen(f.seed == 0 ? rd() : f.seed);
+  std::uniform_real_distribution<> dx(bb.min_x, bb.max_x), dy(bb.min_y, bb.max_y);
+  std::vector<int64_t> pts;
+  for (int i = 0; i < f.gen_n; i++) {
+    double x = dx(gen), y = dy(gen);
+    pts.push_back(sc.ScaleX(x)); pts.push_back(sc.ScaleY(y));
+  }
+  return pts;
+}
+
+void CheckMode(const Flags& f) {
+  if (f.mode == "lbvh") return;
+  if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
+  if (f.mode == "grid") throw std::runtime_error("-mode=grid is the CPU parity oracle of this repository (oracle/), not a product path: use -mode=lbvh");
+  throw std::runtime_error("Invalid index type: " + f.mode);
+}
+
+void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
+  PhaseTimer tm;
+  tm.start();
+  tm.next("Read map 0");
+  auto base = load_from(f.poly1, f.serialize, f.v);
+  std::unique_ptr<Context> ctx;
+  std::shared_ptr<HostMap> gen_queries;
+  if (f.poly2.empty()) {
+    tm.next("Generate Workloads");
+    ctx.reset(new Context({base, nullptr}, f.device));
+    gen_queries = GenerateLSIQueries(f, *ctx);
+  } else {
+    tm.next("Read map 1");
+    auto query = load_from(f.poly2, f.serialize, f.v);
+    ctx.reset(new Context({base, query}, f.device));
+  }
+  tm.next("Create App");
+  LSILBVH lsi(*ctx);
+  tm.next("Load Data");
+  ctx->LoadToDevice();
+  if (gen_queries) ctx->set_map(1, gen_queries);
+  tm.next("Init");
+  size_t queue_cap = (size_t) ((ctx->get_map(0)->n_edges() + ctx->get_map(1)->n_edges()) * f.xsect_factor);
+  std::cerr << "Queue capacity: " << queue_cap << std::endl;
+  lsi.Init(queue_cap);
+  tm.next("Build Index");
+  rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
+  tm.next("Warmup");
+  for (int i = 0; i < f.warmup; i++) lsi.Query(1);
+  tm.next("Query", f.repeat);
+  float kernel_ms = 0;
+  for (int i = 0; i < f.repeat; i++) {
+    if (f.v) std::cerr << "Iter: " << i << std::endl;
+    lsi.Query(1);
+    float ms = 0;
+    rj_last_ms(ctx->handle(), RJ_T_LSI_KERNEL, &ms);
+    kernel_ms += ms;
+  }
+  tm.next("Cleanup");
+  std::cerr << "Intersections: " << lsi.size() << " Queue Load Factor: " << (double) lsi.size() / (queue_cap ? queue_cap : 1)
+            << std::endl;
+  if (f.repeat > 0) std::cerr << "LSI kernel (HIP events): " << kernel_ms / f.repeat << " ms" << std::endl;
+  if (!f.output.empty()) {
+    std::vector<rj_xsect> xs;
+    lsi.CopyTo(xs);
+    FILE* fp = fopen(f.output.c_str(), "w");
+    if (!fp) throw std::runtime_error("Cannot write " + f.output);
+    for (auto& x : xs) fprintf(fp, "%u %u %ld %ld\n", x.eid[0], x.eid[1], (long) x.x_num, (long) x.y_num);
+    fclose(fp);
+  }
+  tm.end();
+}
+
+void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
+  PhaseTimer tm;
+  tm.start();
+  tm.next("Read map 0");
+  auto base = load_from(f.poly1, f.serialize, f.v);
+  std::unique_ptr<Context> ctx;
+  std::vector<int64_t> gen_pts;
+  int64_t* d_pts = nullptr;
+  size_t n_points = 0;
+  if (f.poly2.empty()) {
+    tm.next("Generate Workloads");
+    ctx.reset(new Context({base, nullptr}, f.device));
+    gen_pts = GeneratePIPQueries(f, *ctx);
+    tm.next("Load Data");
+    ctx->LoadToDevice();
+    n_points = gen_pts.size() / 2;
+    rj_check(ctx->handle(), rj_dev_alloc(ctx->handle(), 16 * (n_points ? n_points : 1), (void**) &d_pts), "rj_dev_alloc");
+    rj_check(ctx->handle(), rj_memcpy_h2d(ctx->handle(), d_pts, gen_pts.data(), 16 * n_points), "rj_memcpy_h2d");
+  } else {
+    tm.next("Read map 1");
+    auto query = load_from(f.poly2, f.serialize, f.v);
+    ctx.reset(new Context({base, query}, f.device));
+    tm.next("Load Data");
+    ctx->LoadToDevice();
+    n_points = ctx->get_map(1)->n_points();
+  }
+  tm.next("Create App");
+  PIPLBVH pip(*ctx);
+  tm.next("Init");
+  pip.Init(n_points);
+  tm.next("Build Index");
+  rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
+  tm.next("Warmup");
+  for (int i = 0; i < f.warmup; i++) pip.Query(1, d_pts, n_points);
+  tm.next("Query", f.repeat);
+  float kernel_ms = 0;
+  for (int i = 0; i < f.repeat; i++) {
+    pip.Query(1, d_pts, n_points);
+    float ms = 0;
+    rj_last_ms(ctx->handle(), RJ_T_PIP_KERNEL, &ms);
+    kernel_ms += ms;
+  }
+  tm.next("Cleanup");
+  std::vector<uint32_t> eids;
+  pip.get_closest_eids(eids);
+  size_t hits = 0;
+  for (auto e : eids) hits += e != RJ_MISS_EID;
+  std::cerr << "Points: " << n_points << " Hits: " << hits << std::endl;
+  if (f.repeat > 0) std::cerr << "PIP kernel (HIP events): " << kernel_ms / f.repeat << " ms" << std::endl;
+  if (!f.output.empty()) {
+    std::vector<int32_t> faces;
+    pip.get_face_ids(faces);
+    FILE* fp = fopen(f.output.c_str(), "w");
+    if (!fp) throw std::runtime_error("Cannot write " + f.output);
+    for (size_t i = 0; i < eids.size(); i++) fprintf(fp, "%u %d\n", eids[i], faces[i]);
+    fclose(fp);
+  }
+  if (d_pts) rj_dev_free(ctx->handle(), d_pts);
+  tm.end();
+}
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+  if (argc == 1) {
+    Usage(argv[0]);
+    return 1;
+  }
+  Flags f;
+  try {
+    f.Parse(argc, argv);
+    if (f.poly1.empty()) throw std::invalid_argument("-poly1 is required");
+    CheckMode(f);
+    if (f.query == "lsi") RunLSIQuery(f);
+    else if (f.query == "pip") RunPIPQuery(f);
+    else throw std::invalid_argument("Invalid query: " + f.query);
+  } catch (const std::invalid_argument& e) {
+    std::cerr << "ERROR: " << e.what() << std::endl;
+    Usage(argv[0]);
+    return 2;
+  } catch (const std::exception& e) {
+    std::cerr << "FATAL: " << e.what() << std::endl;
+    return 3;
+  }
+  return 0;
+}

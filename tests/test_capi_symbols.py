@@ -46,5 +46,7 @@ def test_product_never_imports_oracle():
         for fn in fns:
             if fn.endswith((".py", ".hip", ".h", ".cc", ".cpp")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
-                assert "rjoracle" not in txt and "rj_oracle" not in txt and "import oracle" not in txt \
-                    and "from oracle" not in txt and "oracle/" not in txt, os.path.join(dp, fn)
+                for needle in ("rjoracle", "rj_oracle", "import oracle", "from oracle", "librj_oracle",
+                               "liblsi_ref", "_ref/"):
+                    assert needle not in txt, "%s references the oracle (%s)" % (os.path.join(dp, fn), needle)
+                assert not re.search(r'#include\s*[<"][^>"]*oracle', txt), os.path.join(dp, fn)

@@ -1,0 +1,73 @@
+"""N>1 host logic on CPU: world_size-2 and -3 gloo runs of the sharding + all-gather-v code that
+bench.py uses on RCCL.  The per-shard 'operator' here is the oracle (test infrastructure) so the
+exchange logic is checked without a GPU: union of shard results == whole-map result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import rjoracle as O
+    from rayjoin_amd import dist as rjd
+    from rayjoin_amd import maps, synth
+    O.lib().rjo_set_num_threads(2)
+    ctx = maps.Context([synth.lattice_map(5, 70, 41), synth.lattice_map(11, 33, 42)]).load()
+    base, query = ctx.maps
+    sh = rjd.shard_of(query, world, rank)
+    m0 = O.Map(base.pts, base.row_index, base.left, base.right)
+    m1 = O.Map(query.pts, query.row_index, query.left, query.right)
+    whole = O.lsi_brute(m0, m1)
+    e0, e1 = sh["eids"]
+    mine = whole[(whole[:, 1] >= e0) & (whole[:, 1] < e1)]
+    cap = len(whole) + 8
+    buf = torch.zeros((cap, 2), dtype=torch.int32)
+    buf[:len(mine)] = torch.from_numpy(mine.astype(np.int32))
+    gathered, counts = rjd.allgather_pairs(buf, len(mine))
+    got = O.sort_pairs(gathered.numpy().astype(np.uint32))
+    assert int(counts.sum()) == len(whole)
+    assert np.array_equal(got, whole), "rank %d: gathered LSI pairs differ from the whole-map result" % rank
+    # PIP: contiguous point shards concatenate back in point order
+    p0, p1 = sh["points"]
+    want = O.pip_brute(m0, 1, query.pts)
+    ids = torch.from_numpy(want[p0:p1].astype(np.int32))
+    max_n = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
+    allids = rjd.allgather_point_results(ids, p1 - p0, max_n)
+    assert np.array_equal(allids.numpy().astype(np.uint32), want)
+    # shards tile the chain range exactly and are balanced by edge count
+    rngs = query.shard_chain_ranges(world)
+    assert rngs[0][0] == 0 and rngs[-1][1] == query.n_chains
+    assert all(rngs[i][1] == rngs[i + 1][0] for i in range(world - 1))
+    sizes = [query.chain_range_to_eids(a, b) for a, b in rngs]
+    ne = [b - a for a, b in sizes]
+    assert sum(ne) == query.n_edges and max(ne) - min(ne) <= 2 * 33
+    open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_and_allgatherv_gloo(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert os.path.exists(tmp_path / ("ok%d" % r))

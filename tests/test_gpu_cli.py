@@ -1,0 +1,51 @@
+"""query_exec end to end on a GPU: the reference's phases, timing format and result counts."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from rayjoin_amd import maps, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "rayjoin_amd", "query_exec")
+
+
+def test_query_exec_lsi_and_pip(oracle, tmp_path):
+    g0, g1 = synth.lattice_map(7, 100, 51), synth.lattice_map(15, 44, 52)
+    p0, p1 = str(tmp_path / "a.cdb"), str(tmp_path / "b.cdb")
+    maps.write_cdb(p0, g0, "%.9f")
+    maps.write_cdb(p1, g1, "%.9f")
+    ctx = maps.Context([maps.read_cdb(p0), maps.read_cdb(p1)]).load()
+    m0 = oracle.Map(ctx.maps[0].pts, ctx.maps[0].row_index, ctx.maps[0].left, ctx.maps[0].right)
+    m1 = oracle.Map(ctx.maps[1].pts, ctx.maps[1].row_index, ctx.maps[1].left, ctx.maps[1].right)
+    want = oracle.lsi_grid(m0, m1, 512)
+    out = str(tmp_path / "pairs.txt")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "lbvh", "-xsect_factor", "0.5",
+                        "-warmup", "1", "-repeat", "2", "-output", out, "-v", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert int(re.search(r"Intersections: (\d+)", r.stderr).group(1)) == len(want)
+    assert "Timing results:" in r.stderr
+    for phase in ("Read map 0", "Read map 1", "Load Data", "Build Index", "Warmup", "Query"):
+        assert re.search(r" - %s: [0-9.e+-]+ ms" % phase, r.stderr), phase
+    got = np.loadtxt(out, dtype=np.int64).reshape(-1, 4)
+    assert np.array_equal(got[:, :2], want["eid"].astype(np.int64))
+    assert np.array_equal(got[:, 2], want["x_num"]) and np.array_equal(got[:, 3], want["y_num"])
+    # PIP: every vertex of map 1
+    outp = str(tmp_path / "pip.txt")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "pip", "-mode", "lbvh", "-warmup", "1",
+                        "-repeat", "1", "-output", outp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    eids = oracle.pip_grid(m0, 0, ctx.maps[1].pts, 512)
+    got = np.loadtxt(outp, dtype=np.int64).reshape(-1, 2)
+    assert np.array_equal(got[:, 0].astype(np.uint32), eids)
+    assert np.array_equal(got[:, 1].astype(np.int32), m0.face_ids(eids))
+    # generated workloads (no -poly2) run and overflow is a reported error, not UB
+    r = subprocess.run([EXE, "-poly1", p0, "-query", "lsi", "-mode", "lbvh", "-gen_n", "2000", "-gen_t", "5",
+                        "-seed", "3", "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Generate Workloads" in r.stderr
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "lbvh", "-xsect_factor", "0.000001",
+                        "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "overflow" in r.stderr
