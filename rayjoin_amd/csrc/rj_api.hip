@@ -32,6 +32,7 @@ struct BvhState {
   Seg* sseg = nullptr;
   uint32_t* seid = nullptr;
   QBox* box0 = nullptr;
+  int32_t* pmx1 = nullptr;
   QBox* lvl[kMaxLevels] = {nullptr};
   uint64_t nlvl[kMaxLevels] = {0};
   uint64_t alloc[kMaxLevels] = {0};
@@ -48,13 +49,14 @@ struct rj_handle_s {
   hipStream_t stream = nullptr;
   MapState map[2];
   BvhState bvh[2];
-  unsigned long long* d_counter = nullptr;  // [1] LSI result count
+  unsigned long long* d_counter = nullptr;  // [0] LSI result count; +128 B: 8 scheduler counters, 128 B apart
   unsigned long long* d_stats = nullptr;    // [4]
   unsigned long long* h_pinned = nullptr;   // [8] pinned read-back area
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
-  int max_blocks = 256 * 8;  // 256 CUs x 8 blocks of 256 threads
+  int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
+  int chunk_groups = 4;      // consecutive 64-query groups handed to a wave at a time
   uint64_t last_stats[16] = {0};
   std::string err;
 };
@@ -95,14 +97,14 @@ void free_map(MapState& m) {
 }
 
 void free_bvh(BvhState& b) {
-  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.box0);
+  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.box0); (void) hipFree(b.pmx1);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
 
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
-  d.sseg = b.sseg; d.seid = b.seid; d.box0 = b.box0;
+  d.sseg = b.sseg; d.seid = b.seid; d.box0 = b.box0; d.pmx1 = b.pmx1;
   for (int l = 0; l < kMaxLevels; l++) { d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l]; }
   d.top = b.top; d.n0 = b.n0;
   return d;
@@ -142,7 +144,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (hipSetDevice(device_id) != hipSuccess) { delete h; return RJ_E_HIP; }
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RJ_E_HIP; }
   h->stream = h->own_stream;
-  bool ok = hipMalloc((void**) &h->d_counter, 8) == hipSuccess &&
+  bool ok = hipMalloc((void**) &h->d_counter, 128 + 8 * 128) == hipSuccess &&
             hipMalloc((void**) &h->d_stats, 128) == hipSuccess &&
             hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess;
   for (int t = 0; ok && t < kNumTimers; t++)
@@ -184,8 +186,13 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!name) return fail(h, RJ_E_INVALID, "null option name");
   if (!strcmp(name, "stats")) { h->stats_on = value != 0; return RJ_OK; }
   if (!strcmp(name, "own_stream")) { h->stream = h->own_stream; return RJ_OK; }
+  if (!strcmp(name, "chunk_groups")) {
+    if (value < 1 || value > 4096) return fail(h, RJ_E_INVALID, "chunk_groups out of range");
+    h->chunk_groups = (int) value;
+    return RJ_OK;
+  }
   if (!strcmp(name, "max_blocks")) {
-    if (value < 1 || value > 65536) return fail(h, RJ_E_INVALID, "max_blocks out of range");
+    if (value < 1 || value > (1 << 20)) return fail(h, RJ_E_INVALID, "max_blocks out of range");
     h->max_blocks = (int) value;
     return RJ_OK;
   }
@@ -283,6 +290,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   if (int r = dev_alloc(h, &b.sseg, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.seid, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.box0, b.n0p)) return r;
+  if (int r = dev_alloc(h, &b.pmx1, b.n0p)) return r;
   for (int l = 1; l <= top; l++)
     if (int r = dev_alloc(h, &b.lvl[l], b.alloc[l])) return r;
   // 1. Morton keys  2. radix sort (key, eid)  3. gather into sorted order + leaf boxes  4. levels
@@ -304,6 +312,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
     }
     if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.ne, b.n0p, b.sseg, b.seid, b.box0)) != hipSuccess) break;
+    if ((e = launch_sort_leaf_blocks(h->stream, b.sseg, b.seid, b.box0, b.pmx1, b.n0p / 64)) != hipSuccess) break;
     const QBox* child = b.box0;
     uint64_t child_alloc = b.n0p;
     for (int l = 1; l <= top; l++) {
@@ -331,7 +340,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (qb > qe || qe > h->map[query_map_id].ne) return fail(h, RJ_E_INVALID, "rj_lsi_query: bad query eid range");
   if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query: null output");
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear (queue.h:125-129)
+  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 128 + 8 * 128, h->stream));  // Queue::Clear (queue.h:125-129) + scheduler
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   LsiArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
@@ -340,6 +349,8 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.base_is_map0 = base_map_id == 0;
   a.out = pairs_dev; a.cap = capacity;
   a.counter = h->d_counter;
+  a.work_counter = (unsigned int*) (h->d_counter + 16);
+  a.chunk_groups = (uint32_t) h->chunk_groups;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_LSI_KERNEL);
   if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, h->max_blocks));
@@ -426,12 +437,15 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   }
   if (int r = set_device(h)) return r;
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
+  RJ_HIP(h, hipMemsetAsync(h->d_counter + 16, 0, 8 * 128, h->stream));
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.base = map_view(h->map[base_map_id]);
   a.pts = pts; a.n = n;
   a.query_map_id = query_map_id;
   a.closest = closest_eid_dev; a.face = face_id_dev;
+  a.work_counter = (unsigned int*) (h->d_counter + 16);
+  a.chunk_groups = (uint32_t) h->chunk_groups;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_PIP_KERNEL);
   if (n) RJ_HIP(h, launch_pip(h->stream, a, h->stats_on, h->max_blocks));

@@ -44,7 +44,8 @@ struct DeviceMap {
 struct DeviceBvh {
   const Seg* sseg;        // [n0p] segments in Morton order (padding = zero segments)
   const uint32_t* seid;   // [n0p] original eid of each sorted slot
-  const QBox* box0;       // [n0p] per-segment boxes (padding = empty)
+  const QBox* box0;       // [n0p] per-segment boxes (padding = empty); sorted by x0 inside each 64-block
+  const int32_t* pmx1;    // [n0p] prefix max of box x1 inside each 64-block
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
   uint32_t nlvl[kMaxLevels];    // real node count per level
   int top;                // top level: nlvl[top] <= 64

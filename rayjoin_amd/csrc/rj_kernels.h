@@ -20,6 +20,8 @@ struct LsiArgs {
   uint32_t* out;       // pairs out [2*cap]
   uint64_t cap;
   unsigned long long* counter;  // result count
+  unsigned int* work_counter;   // dynamic chunk scheduler (zeroed before every launch)
+  uint32_t chunk_groups;        // consecutive 64-query groups per chunk
   unsigned long long* stats;    // [4] or nullptr
 };
 
@@ -31,6 +33,8 @@ struct PipArgs {
   int query_map_id;
   uint32_t* closest;   // [n]
   int32_t* face;       // [n] or nullptr
+  unsigned int* work_counter;
+  uint32_t chunk_groups;
   unsigned long long* stats;
 };
 
@@ -44,6 +48,7 @@ hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const u
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
 hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, uint64_t ne,
                                 uint64_t n0p, Seg* sseg, uint32_t* seid, QBox* box0);
+hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, QBox* box0, int32_t* pmx1, uint64_t nblocks);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks);

@@ -88,6 +88,47 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const Seg* __restrict__ s
   }
 }
 
+
+// Inside a leaf block the order of the 64 segments is free (upper levels only see the union),
+// so each block is sorted by box x0 and gets pmx1[j] = max(x1[0..j]).  A query lane then finds its
+// candidates with a 6-step cross-lane binary search (segments with x0 <= key form a prefix) and
+// a backward scan that stops as soon as pmx1 drops below the query's x -- one or two steps for
+// an x-monotone run of a polyline instead of a 64-iteration uniform loop.
+__global__ __launch_bounds__(256) void k_sort_leaf_blocks(Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
+                                                          QBox* __restrict__ box0, int32_t* __restrict__ pmx1,
+                                                          uint64_t nblocks) {
+  __shared__ int32_t sx1[4][64];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+  for (uint64_t blk = wave; blk < nblocks; blk += nwaves) {
+    const uint64_t i = blk * 64 + lane;
+    const Seg s = sseg[i];
+    const uint32_t id = seid[i];
+    const QBox b = box0[i];
+    int rank = 0;
+    for (int k = 0; k < 64; k++) {
+      const int32_t xk = bcast(b.x0, k);
+      rank += (xk < b.x0 || (xk == b.x0 && k < lane)) ? 1 : 0;
+    }
+    const uint64_t o = blk * 64 + rank;
+    sseg[o] = s;
+    seid[o] = id;
+    box0[o] = b;
+    sx1[wib][rank] = b.x1;
+    wave_lds_fence();
+    int32_t m = sx1[wib][lane];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int32_t t = __shfl_up(m, d, 64);
+      if (lane >= d) m = t > m ? t : m;
+    }
+    pmx1[blk * 64 + lane] = m;
+    wave_lds_fence();
+  }
+}
+
 // one wave per parent node: union of its 64 children
 __global__ __launch_bounds__(256) void k_reduce_level(const QBox* __restrict__ child,
                                                       uint64_t n_child_alloc,
@@ -106,6 +147,43 @@ __global__ __launch_bounds__(256) void k_reduce_level(const QBox* __restrict__ c
     b.y1 = wave_max(b.y1);
     if (lane == 0) parent[p] = b;
   }
+}
+
+
+// number of lanes j with v[j] <= key, for v non-decreasing over the 64 lanes (lane j holds v[j])
+__device__ __forceinline__ int wave_upper_bound(int32_t v, int32_t key) {
+  int k = 0;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    const int32_t probe = __shfl(v, k + step - 1, 64);
+    if (probe <= key) k += step;
+  }
+  const int32_t last = __shfl(v, k, 64);  // k <= 63
+  if (last <= key) k++;
+  return k;
+}
+
+// XCD-aware dynamic scheduler.  The chunk range is cut into 8 contiguous parts, one per XCD
+// (blocks b and b+8 share an XCD under the observed round-robin placement -- speed only, never
+// correctness), each with its own counter on its own cache line.  Waves of one XCD therefore
+// work on neighbouring chunks = neighbouring map regions = the same tree nodes, which stay in
+// that XCD's private 4 MiB L2.  A wave whose part is exhausted steals from the next XCD's part.
+__device__ __forceinline__ bool next_chunk(unsigned int* counters, uint32_t nchunks, int& part, int& tried,
+                                           int lane, uint32_t& chunk_out) {
+  while (tried < 8) {
+    const uint32_t lo = (uint32_t) (((uint64_t) nchunks * part) >> 3);
+    const uint32_t hi = (uint32_t) (((uint64_t) nchunks * (part + 1)) >> 3);
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(&counters[part * 32], 1u);
+    c = __builtin_amdgcn_readfirstlane(c);
+    if (lo + c < hi) {
+      chunk_out = lo + c;
+      return true;
+    }
+    part = (part + 1) & 7;
+    tried++;
+  }
+  return false;
 }
 
 // =============================================================================================
@@ -165,12 +243,11 @@ __device__ __forceinline__ void lsi_drain(LsiWaveLds& L, int& np, int& nh, int n
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
+__global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
   __shared__ LsiWaveLds lds[4];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   LsiWaveLds& L = lds[wib];
-  const uint64_t nwaves = (uint64_t) gridDim.x * 4;
   const uint64_t nq = A.qend - A.qbeg;
   const uint64_t ngroups = (nq + 63) >> 6;
   const DeviceBvh& T = A.bvh;
@@ -179,7 +256,17 @@ __global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
   long long tk_node = 0, tk_leaf = 0, tk_head = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
-  for (uint64_t g = (uint64_t) blockIdx.x * 4 + wib; g < ngroups; g += nwaves) {
+  // Dynamic scheduling in chunks of consecutive groups: consecutive groups of a chain walk almost
+  // the same tree nodes, so a chunk re-hits them in this CU's L1/L2 instead of the Infinity Cache;
+  // the atomic hands the next chunk to whichever wave is free (no tail).
+  const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
+  int part = blockIdx.x & 7, tried = 0;
+  for (;;) {
+  uint32_t chunk = 0;
+  if (!next_chunk(A.work_counter, nchunks, part, tried, lane, chunk)) break;
+  const uint64_t g_begin = (uint64_t) chunk * A.chunk_groups;
+  const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
+  for (uint64_t g = g_begin; g < g_end; g++) {
     const long long tkg = STATS ? clock64() : 0;
     const uint64_t q = A.qbeg + g * 64 + lane;
     const bool valid = q < A.qend;
@@ -232,30 +319,35 @@ __global__ __launch_bounds__(256) void k_lsi(LsiArgs A) {
         wave_lds_fence();
         if (STATS) tk_node += clock64() - tk0;
       } else {
-        // leaf block: 64 base segments, one box per lane
+        // leaf block: 64 base segments sorted by x0, one per lane.  Each query lane binary-searches
+        // the prefix with x0 <= its x1 and scans it backwards while pmx1 says an x-overlap is
+        // still possible.
         const uint32_t slot0 = idx * 64;
-        QBox bb = T.box0[(uint64_t) slot0 + lane];
-        uint64_t bm = __ballot(overlap(bb, gx0, gy0, gx1, gy1));
+        const QBox bb = T.box0[(uint64_t) slot0 + lane];
+        const int32_t pm = T.pmx1[(uint64_t) slot0 + lane];
         if (STATS) st_leaf++;
-        while (bm) {
-          const int b = __builtin_ctzll(bm);
-          bm &= bm - 1;
-          const int32_t bx0 = bcast(bb.x0, b), by0 = bcast(bb.y0, b);
-          const int32_t bx1 = bcast(bb.x1, b), by1 = bcast(bb.y1, b);
-          // (invalid lanes hold an empty box and can never overlap)
-          const bool c = qx0 <= bx1 && bx0 <= qx1 && qy0 <= by1 && by0 <= qy1;
+        int j = wave_upper_bound(bb.x0, qx1) - 1;  // invalid lanes: qx1 = -1 -> j = -1
+        for (;;) {
+          const int jj = j < 0 ? 0 : j;
+          const int32_t pmj = __shfl(pm, jj, 64);
+          const bool act = j >= 0 && pmj >= qx0;
+          if (!__ballot(act)) break;
+          const int32_t sx1 = __shfl(bb.x1, jj, 64), sy0 = __shfl(bb.y0, jj, 64), sy1 = __shfl(bb.y1, jj, 64);
+          const bool c = act && sx1 >= qx0 && qy0 <= sy1 && sy0 <= qy1;  // (x0[j] <= qx1 by construction)
           const uint64_t cm = __ballot(c);
           if (STATS) st_box++;
           if (cm) {
-            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q, slot0 + b);
+            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q, slot0 + (uint32_t) jj);
             np += __popcll(cm);
             wave_lds_fence();
             if (np >= 64) lsi_drain<STATS>(L, np, nh, 64, A, lane, st_tests);
           }
+          j--;
         }
         if (STATS) tk_leaf += clock64() - tk0;
       }
     }
+  }
   }
   if (np > 0) lsi_drain<STATS>(L, np, nh, np, A, lane, st_tests);
   if (nh >= 64) lsi_flush_hits<STATS>(L, nh, 64, A, lane);
@@ -309,42 +401,47 @@ __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, u
 }
 
 // =============================================================================================
-// PIP: upward ray through the same tree; per-lane best with pruning; compacted (point, edge)
-// candidates evaluated densely and merged back through an LDS mailbox
+// PIP: upward ray through the same tree.
+//   * pruning is integer-only and sound: a base segment whose quantised box strictly contains the
+//     point's x and lies strictly above the point is a CERTAIN hit (exact x-range test passes,
+//     diff_y < 0 with margin), so its box top bounds the lane's best from above;
+//   * candidates go to per-lane lists in LDS ([k][lane]: bank = lane, conflict-free) and are
+//     evaluated exactly by their own lane -- no cross-lane merge;
+//   * the leaf loop runs over whichever side is smaller: relevant base segments (lanes =
+//     points) or relevant points (lanes = base segments).
 // =============================================================================================
+constexpr int kPipList = 8;     // candidate slots per lane between two exact-evaluation rounds
+constexpr int kPipStack = 64 * 4;  // >= 63 * (levels - 1) + 64 entries for <= 4 expanded levels
+
+// A stack entry carries the node's y0 and the mask of lanes that could use it when it was pushed,
+// so a stale entry (every interested lane has since found something lower) is dropped at pop time
+// without touching memory.
 struct PipWaveLds {
-  uint32_t stack[kStackEntries];
-  uint2 pairs[kPairBuf];  // (query lane, sorted base slot)
-  uint32_t mailbox[64];
-  double res_yy[64];
-  double res_slope[64];
-  uint32_t res_eid[64];
+  uint4 stack[kPipStack];  // {level<<28 | index, y0, lane mask lo, lane mask hi}
+  uint32_t cand[kPipList][64];
 };
 
-
-__device__ __forceinline__ int32_t quant_best(double yy) {
-  // conservative quantised upper bound of a finite best y (+1 margin, see DESIGN.md "PIP pruning")
-  double t = (yy + (double) kCoordOffset) * (1.0 / 65536.0);
-  if (!(t < 2147483000.0)) return 0x7FFFFFFF;
-  if (t < -1.0) return -1;
-  return (int32_t) t + 1;
-}
-
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_pip(PipArgs A) {
+__global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
   __shared__ PipWaveLds lds[4];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   PipWaveLds& L = lds[wib];
-  const uint64_t nwaves = (uint64_t) gridDim.x * 4;
   const uint64_t ngroups = (A.n + 63) >> 6;
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
-  long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_total = 0, tk_rounds = 0;  // STATS: cycle stamps
+  long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_rounds = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
-  for (uint64_t g = (uint64_t) blockIdx.x * 4 + wib; g < ngroups; g += nwaves) {
+  const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
+  int part = blockIdx.x & 7, tried = 0;
+  for (;;) {  // XCD-aware dynamic chunked scheduling, see next_chunk
+  uint32_t chunk = 0;
+  if (!next_chunk(A.work_counter, nchunks, part, tried, lane, chunk)) break;
+  const uint64_t g_begin = (uint64_t) chunk * A.chunk_groups;
+  const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
+  for (uint64_t g = g_begin; g < g_end; g++) {
     const uint64_t ip = g * 64 + lane;
     const bool valid = ip < A.n;
     int64_t px = 0, py = 0;
@@ -358,62 +455,42 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
     const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
     double best_yy = __builtin_inf(), best_slope = 0.0;
     uint32_t best_eid = 0xFFFFFFFFu;
-    int32_t lane_qbest = valid ? 0x7FFFFFFF : -1;  // quantised bound on this lane's best y
-    int32_t gbest = 0x7FFFFFFF;                    // wave max of lane_qbest
-    int np = 0;
-    L.mailbox[lane] = 0xFFFFFFFFu;
+    int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer
+    int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
+    int cnt = 0;                              // this lane's candidate-list fill
 
-    auto drain = [&](int n) {
-      // evaluate the top n (<= 64) candidates densely, then deliver results to their query lane
+    // every lane evaluates its own candidate list exactly (pip.h:36-95), then clears it
+    auto evaluate = [&]() {
       const long long tk0 = STATS ? clock64() : 0;
-      bool pending = false;
-      int ql = 0;
-      double yy = 0, slope = 0;
-      uint32_t eid = 0;
-      uint2 pr = make_uint2(0, 0);
-      if (lane < n) pr = L.pairs[np - n + lane];
-      ql = (int) pr.x;
-      // the query lane's point (all lanes take part in the shuffle)
-      const int64_t qpx = ((int64_t) __shfl((int) (px >> 32), ql, 64) << 32) |
-                          (uint32_t) __shfl((int) (uint32_t) px, ql, 64);
-      const int64_t qpy = ((int64_t) __shfl((int) (py >> 32), ql, 64) << 32) |
-                          (uint32_t) __shfl((int) (uint32_t) py, ql, 64);
-      if (lane < n) {
-        Seg bs = T.sseg[pr.y];
-        eid = T.seid[pr.y];
-        pending = pip_eval(bs, qpx, qpy, qm, &yy, &slope);
-      }
-      np -= n;
-      if (STATS) st_tests += n;
-      while (__ballot(pending)) {
-        if (STATS) tk_rounds++;
-        if (pending) L.mailbox[ql] = (uint32_t) lane;  // one winner per query lane
-        wave_lds_fence();
-        const bool win = pending && L.mailbox[ql] == (uint32_t) lane;
-        if (win) {
-          L.res_yy[ql] = yy;
-          L.res_slope[ql] = slope;
-          L.res_eid[ql] = eid;
-        }
-        wave_lds_fence();
-        if (L.mailbox[lane] != 0xFFFFFFFFu) {
-          const double ryy = L.res_yy[lane], rsl = L.res_slope[lane];
-          const uint32_t reid = L.res_eid[lane];
-          if (pip_better(ryy, rsl, reid, best_yy, best_slope, best_eid, qm)) {
-            best_yy = ryy; best_slope = rsl; best_eid = reid;
+      const int maxc = wave_max(cnt);
+      for (int r = 0; r < maxc; r++) {
+        if (r < cnt) {
+          const uint32_t slot = L.cand[r][lane];
+          const Seg bs = T.sseg[slot];
+          const uint32_t eid = T.seid[slot];
+          double yy, slope;
+          if (pip_eval(bs, px, py, qm, &yy, &slope) &&
+              pip_better(yy, slope, eid, best_yy, best_slope, best_eid, qm)) {
+            best_yy = yy; best_slope = slope; best_eid = eid;
           }
-          L.mailbox[lane] = 0xFFFFFFFFu;
         }
-        pending = pending && !win;
-        wave_lds_fence();
+        if (STATS) tk_rounds++;
       }
-      if (valid && best_eid != 0xFFFFFFFFu) lane_qbest = quant_best(best_yy);
-      gbest = wave_max(lane_qbest);
+      if (STATS) st_tests += (unsigned long long) __popcll(__ballot(cnt > 0));
+      cnt = 0;
+      if (best_eid != 0xFFFFFFFFu) {
+        // exact best known: tighten the integer bound (conservative: +1 quantum)
+        double t = (best_yy + (double) kCoordOffset) * (1.0 / 65536.0);
+        int32_t qb = t < 2147483000.0 ? (t < -1.0 ? -1 : (int32_t) t + 1) : 0x7FFFFFFF;
+        qbest = qb < qbest ? qb : qbest;
+      }
+      gbest = wave_max(qbest);
       if (STATS) tk_drain += clock64() - tk0;
     };
 
-    // push-time per-lane culling (see k_lsi): a child survives only if SOME lane's upward ray
-    // can still hit it given that lane's current best
+    // a child survives only if SOME lane's upward ray can still hit it; the lanes that can are
+    // remembered per child (mlo/mhi of the lane holding that child) for the pop-time re-check
+    uint32_t mlo = 0, mhi = 0;
     auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
       uint64_t keep = 0;
       while (um) {
@@ -421,32 +498,48 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
         um &= um - 1;
         const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        if (__ballot(cx0 <= qx && qx <= cx1 && cy1 >= qy - 1 && cy0 <= lane_qbest)) keep |= 1ull << c;
+        const uint64_t bal = __ballot(cx0 <= qx && qx <= cx1 && cy1 >= qy - 1 && cy0 <= qbest);
+        if (bal) {
+          keep |= 1ull << c;
+          if (lane == c) {
+            mlo = (uint32_t) bal;
+            mhi = (uint32_t) (bal >> 32);
+          }
+        }
       }
       return keep;
     };
+
     int sp = 0;
     {
       QBox b = T.lvl[T.top][lane];
       uint64_t m = refine(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
-      const int cnt = __popcll(m);
+      const int n = __popcll(m);
       // reversed so that lane 0's child (lowest Morton = lowest y half) pops first
-      if ((m >> lane) & 1) L.stack[cnt - 1 - rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
-      sp = cnt;
+      if ((m >> lane) & 1)
+        L.stack[n - 1 - rank_below(m)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, mlo, mhi);
+      sp = n;
       wave_lds_fence();
     }
     while (sp > 0) {
-      uint32_t e = __builtin_amdgcn_readfirstlane(L.stack[sp - 1]);
+      const uint4 ent = L.stack[sp - 1];
       --sp;
+      const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
+      const int32_t ey0 = (int32_t) __builtin_amdgcn_readfirstlane(ent.y);
+      const uint64_t emask = ((uint64_t) __builtin_amdgcn_readfirstlane(ent.w) << 32) | __builtin_amdgcn_readfirstlane(ent.z);
+      // stale?  (every lane that wanted this node has a bound below it by now)
+      if (!__ballot(((emask >> lane) & 1) && ey0 <= qbest)) continue;
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
       if (lvl > 1) {
         const long long tk0 = STATS ? clock64() : 0;
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
         uint64_t m = refine(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
-        const int cnt = __popcll(m);
-        if ((m >> lane) & 1) L.stack[sp + cnt - 1 - rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
-        sp += cnt;
+        const int n = __popcll(m);
+        if ((m >> lane) & 1)
+          L.stack[sp + n - 1 - rank_below(m)] =
+              make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, mlo, mhi);
+        sp += n;
         if (STATS) st_nodes++;
         wave_lds_fence();
         if (STATS) tk_node += clock64() - tk0;
@@ -454,31 +547,35 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
         const long long tk0 = STATS ? clock64() : 0;
         const long long tkd0 = tk_drain;
         const uint32_t slot0 = idx * 64;
-        QBox bb = T.box0[(uint64_t) slot0 + lane];
-        uint64_t bm = __ballot(bb.x0 <= gx1 && gx0 <= bb.x1 && bb.y1 >= gy0 - 1 && bb.y0 <= gbest);
+        const QBox bb = T.box0[(uint64_t) slot0 + lane];  // one base segment per lane, sorted by x0
+        const int32_t pm = T.pmx1[(uint64_t) slot0 + lane];
         if (STATS) st_leaf++;
-        while (bm) {
-          const int b = __builtin_ctzll(bm);
-          bm &= bm - 1;
-          const int32_t bx0 = bcast(bb.x0, b), by0 = bcast(bb.y0, b);
-          const int32_t bx1 = bcast(bb.x1, b), by1 = bcast(bb.y1, b);
-          const bool c = bx0 <= qx && qx <= bx1 && by1 >= qy - 1 && by0 <= lane_qbest;
-          const uint64_t cm = __ballot(c);
-          if (STATS) st_box++;
-          if (cm) {
-            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) lane, slot0 + b);
-            np += __popcll(cm);
-            wave_lds_fence();
-            if (np >= 64) drain(64);
+        // lanes whose ray cannot use this block any more (or never could) sit the visit out
+        const bool want = ((emask >> lane) & 1) && ey0 <= qbest;
+        const int ub = wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
+        int j = want ? ub - 1 : -1;
+        for (;;) {
+          const int jj = j < 0 ? 0 : j;
+          const int32_t pmj = __shfl(pm, jj, 64);
+          const bool act = j >= 0 && pmj >= qx;
+          if (!__ballot(act)) break;
+          const int32_t sx0 = __shfl(bb.x0, jj, 64), sx1 = __shfl(bb.x1, jj, 64);
+          const int32_t sy0 = __shfl(bb.y0, jj, 64), sy1 = __shfl(bb.y1, jj, 64);
+          if (act && sx1 >= qx && sy1 >= qy - 1 && sy0 <= qbest) {
+            L.cand[cnt][lane] = slot0 + (uint32_t) jj;
+            cnt++;
+            // certain hit (strictly inside in x, strictly above) => its box top bounds the answer
+            if (sx0 < qx && qx < sx1 && sy0 > qy && sy1 < qbest - 1) qbest = sy1 + 1;
           }
+          if (STATS) st_box++;
+          if (__ballot(cnt >= kPipList)) evaluate();
+          j--;
         }
-        // drain eagerly: the sooner a lane knows its best, the more of the column above it is
-        // pruned (a partial drain costs far less than one more leaf block)
-        if (np > 0) drain(np);
+        gbest = wave_max(qbest);
         if (STATS) tk_leaf += (clock64() - tk0) - (tk_drain - tkd0);
       }
     }
-    if (np > 0) drain(np);
+    evaluate();
     if (valid) {
       A.closest[ip] = best_eid;
       if (A.face) {
@@ -492,8 +589,9 @@ __global__ __launch_bounds__(256) void k_pip(PipArgs A) {
       }
     }
   }
+  }
   if (STATS && lane == 0 && A.stats) {
-    tk_total = clock64() - tk_begin;
+    const long long tk_total = clock64() - tk_begin;
     atomicAdd(&A.stats[0], st_leaf);
     atomicAdd(&A.stats[1], st_tests);
     atomicAdd(&A.stats[2], st_nodes);
@@ -554,6 +652,11 @@ hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* 
   return hipGetLastError();
 }
 
+hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, QBox* box0, int32_t* pmx1, uint64_t nblocks) {
+  hipLaunchKernelGGL(k_sort_leaf_blocks, dim3(grid_for(nblocks, 4, 8192)), dim3(256), 0, st, sseg, seid, box0, pmx1, nblocks);
+  return hipGetLastError();
+}
+
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc) {
   hipLaunchKernelGGL(k_reduce_level, dim3(grid_for(n_parent_alloc, 4, 8192)), dim3(256), 0, st, child,
@@ -561,9 +664,22 @@ hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_chi
   return hipGetLastError();
 }
 
+static int resident_blocks(const void* kernel, int max_blocks) {
+  int dev = 0, cus = 256, per_cu = 4;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  int b = cus * per_cu;
+  return b < max_blocks ? b : max_blocks;
+}
+
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks) {
   uint64_t ngroups = (a.qend - a.qbeg + 63) / 64;
-  int grid = grid_for(ngroups, 4, max_blocks);
+  uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+  const void* k = stats ? (const void*) k_lsi<true> : (const void*) k_lsi<false>;
+  static int res[2] = {0, 0};
+  if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
+  int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
     hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a);
   else
@@ -580,7 +696,11 @@ hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, c
 
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks) {
   uint64_t ngroups = (a.n + 63) / 64;
-  int grid = grid_for(ngroups, 4, max_blocks);
+  uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+  const void* k = stats ? (const void*) k_pip<true> : (const void*) k_pip<false>;
+  static int res[2] = {0, 0};
+  if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
+  int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
     hipLaunchKernelGGL(k_pip<true>, dim3(grid), dim3(256), 0, st, a);
   else
