@@ -33,6 +33,7 @@ struct BvhState {
   uint32_t* seid = nullptr;
   QBox* box0 = nullptr;
   int32_t* pmx1 = nullptr;
+  uint32_t* occ = nullptr;
   QBox* lvl[kMaxLevels] = {nullptr};
   uint64_t nlvl[kMaxLevels] = {0};
   uint64_t alloc[kMaxLevels] = {0};
@@ -97,14 +98,14 @@ void free_map(MapState& m) {
 }
 
 void free_bvh(BvhState& b) {
-  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.box0); (void) hipFree(b.pmx1);
+  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.occ);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
 
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
-  d.sseg = b.sseg; d.seid = b.seid; d.box0 = b.box0; d.pmx1 = b.pmx1;
+  d.sseg = b.sseg; d.seid = b.seid; d.box0 = b.box0; d.pmx1 = b.pmx1; d.occ = b.occ;
   for (int l = 0; l < kMaxLevels; l++) { d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l]; }
   d.top = b.top; d.n0 = b.n0;
   return d;
@@ -291,6 +292,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   if (int r = dev_alloc(h, &b.seid, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.box0, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.pmx1, b.n0p)) return r;
+  if (int r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords)) return r;
   for (int l = 1; l <= top; l++)
     if (int r = dev_alloc(h, &b.lvl[l], b.alloc[l])) return r;
   // 1. Morton keys  2. radix sort (key, eid)  3. gather into sorted order + leaf boxes  4. levels
@@ -312,6 +314,8 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
     }
     if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.ne, b.n0p, b.sseg, b.seid, b.box0)) != hipSuccess) break;
+    if ((e = hipMemsetAsync(b.occ, 0, (size_t) kOccDim * kOccRowWords * 4, h->stream)) != hipSuccess) break;
+    if ((e = launch_mark_occupancy(h->stream, b.box0, b.n0p, b.occ)) != hipSuccess) break;
     if ((e = launch_sort_leaf_blocks(h->stream, b.sseg, b.seid, b.box0, b.pmx1, b.n0p / 64)) != hipSuccess) break;
     const QBox* child = b.box0;
     uint64_t child_alloc = b.n0p;

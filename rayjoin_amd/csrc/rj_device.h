@@ -25,6 +25,9 @@ constexpr int kStackEntries = 64 * 5 + 64;
 constexpr int kPairBuf = 128;          // >= 64 (carry) + 64 (one append step)
 constexpr int kQuantShift = 16;
 constexpr int64_t kCoordOffset = (int64_t) 1 << 46;
+constexpr int kOccShift = 19;                  // 31-bit quantised coordinate -> 12-bit cell
+constexpr int kOccDim = 1 << (31 - kOccShift);  // 4096 x 4096 cells = 2 MiB of bits
+constexpr int kOccRowWords = kOccDim / 32;
 constexpr int32_t kEmptyMin = 0x7FFFFFFF;
 constexpr int32_t kEmptyMax = -1;
 
@@ -46,6 +49,7 @@ struct DeviceBvh {
   const uint32_t* seid;   // [n0p] original eid of each sorted slot
   const QBox* box0;       // [n0p] per-segment boxes (padding = empty); sorted by x0 inside each 64-block
   const int32_t* pmx1;    // [n0p] prefix max of box x1 inside each 64-block
+  const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
   uint32_t nlvl[kMaxLevels];    // real node count per level
   int top;                // top level: nlvl[top] <= 64

@@ -89,6 +89,41 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const Seg* __restrict__ s
 }
 
 
+// Occupancy bitmap of the indexed map: every cell a segment's quantised box touches is set.
+// Two boxes that overlap share a point, hence a cell, so "no set bit under the query box" proves
+// the query can have no candidate: the LSI kernel drops such lanes before the traversal (most of
+// a sparse join) and, when a whole group is clear, skips the tree with ONE gather.
+__global__ __launch_bounds__(256) void k_mark_occupancy(const QBox* __restrict__ box0, uint64_t n0,
+                                                        uint32_t* __restrict__ occ) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n0;
+       i += (uint64_t) gridDim.x * blockDim.x) {
+    const QBox b = box0[i];
+    if (b.x1 < b.x0) continue;  // padding
+    const int cx0 = b.x0 >> kOccShift, cx1 = b.x1 >> kOccShift;
+    const int cy0 = b.y0 >> kOccShift, cy1 = b.y1 >> kOccShift;
+    for (int cy = cy0; cy <= cy1; cy++)
+      for (int w = cx0 >> 5; w <= (cx1 >> 5); w++) {
+        const int lo = w == (cx0 >> 5) ? (cx0 & 31) : 0;
+        const int hi = w == (cx1 >> 5) ? (cx1 & 31) : 31;
+        const uint32_t mask = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        uint32_t* word = &occ[(size_t) cy * kOccRowWords + w];
+        // neighbouring segments set the same bits: look (past the L1) before paying an atomic
+        if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) != mask) atomicOr(word, mask);
+      }
+  }
+}
+
+__device__ __forceinline__ bool occ_any(const uint32_t* __restrict__ occ, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
+  const int cx0 = x0 >> kOccShift, cx1 = x1 >> kOccShift;
+  const int cy0 = y0 >> kOccShift, cy1 = y1 >> kOccShift;
+  if (cx1 - cx0 > 1 || cy1 - cy0 > 1) return true;  // large box: let the tree decide
+  const uint32_t a = occ[(size_t) cy0 * kOccRowWords + (cx0 >> 5)] >> (cx0 & 31);
+  const uint32_t b = occ[(size_t) cy0 * kOccRowWords + (cx1 >> 5)] >> (cx1 & 31);
+  const uint32_t c = occ[(size_t) cy1 * kOccRowWords + (cx0 >> 5)] >> (cx0 & 31);
+  const uint32_t d = occ[(size_t) cy1 * kOccRowWords + (cx1 >> 5)] >> (cx1 & 31);
+  return ((a | b | c | d) & 1u) != 0;
+}
+
 // Inside a leaf block the order of the 64 segments is free (upper levels only see the union),
 // so each block is sorted by box x0 and gets pmx1[j] = max(x1[0..j]).  A query lane then finds its
 // candidates with a 6-step cross-lane binary search (segments with x0 <= key form a prefix) and
@@ -277,6 +312,13 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
       qx1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
       qy0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
       qy1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+      if (!occ_any(T.occ, qx0, qy0, qx1, qy1)) {  // nothing of the base map near this segment
+        qx0 = kEmptyMin; qy0 = kEmptyMin; qx1 = kEmptyMax; qy1 = kEmptyMax;
+      }
+    }
+    if (!__ballot(qx0 <= qx1)) {  // the whole group is clear of the base map
+      if (STATS) tk_head += clock64() - tkg;
+      continue;
     }
     const int32_t gx0 = wave_min(qx0), gy0 = wave_min(qy0);
     const int32_t gx1 = wave_max(qx1), gy1 = wave_max(qy1);
@@ -654,6 +696,11 @@ hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* 
 
 hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, QBox* box0, int32_t* pmx1, uint64_t nblocks) {
   hipLaunchKernelGGL(k_sort_leaf_blocks, dim3(grid_for(nblocks, 4, 8192)), dim3(256), 0, st, sseg, seid, box0, pmx1, nblocks);
+  return hipGetLastError();
+}
+
+hipError_t launch_mark_occupancy(hipStream_t st, const QBox* box0, uint64_t n0, uint32_t* occ) {
+  hipLaunchKernelGGL(k_mark_occupancy, dim3(grid_for(n0, 256, 8192)), dim3(256), 0, st, box0, n0, occ);
   return hipGetLastError();
 }
 
