@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
   const DeviceBvh& T = A.bvh;
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
-  long long tk_node = 0, tk_leaf = 0, tk_head = 0;  // STATS: cycle stamps
+  long long tk_node = 0, tk_leaf = 0, tk_head = 0, tk_sched = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
   // Dynamic scheduling in chunks of consecutive groups: consecutive groups of a chain walk almost
@@ -298,7 +298,9 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
   int part = blockIdx.x & 7, tried = 0;
   for (;;) {
   uint32_t chunk = 0;
+  const long long tks = STATS ? clock64() : 0;
   if (!next_chunk(A.work_counter, nchunks, part, tried, lane, chunk)) break;
+  if (STATS) tk_sched += clock64() - tks;
   const uint64_t g_begin = (uint64_t) chunk * A.chunk_groups;
   const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
   for (uint64_t g = g_begin; g < g_end; g++) {
@@ -307,7 +309,12 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
     const bool valid = q < A.qend;
     int32_t qx0 = kEmptyMin, qy0 = kEmptyMin, qx1 = kEmptyMax, qy1 = kEmptyMax;
     if (valid) {
-      Seg s = A.qseg[q];
+      Seg s;  // streamed once
+      const int64_t* sp64 = reinterpret_cast<const int64_t*>(A.qseg + q);
+      s.x1 = __builtin_nontemporal_load(sp64);
+      s.y1 = __builtin_nontemporal_load(sp64 + 1);
+      s.x2 = __builtin_nontemporal_load(sp64 + 2);
+      s.y2 = __builtin_nontemporal_load(sp64 + 3);
       qx0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
       qx1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
       qy0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
     atomicAdd(&A.stats[5], (unsigned long long) tk_node);
     atomicAdd(&A.stats[6], (unsigned long long) tk_leaf);  // includes the dense predicate phase
     atomicAdd(&A.stats[7], (unsigned long long) tk_head);  // group load + union box + top level
+    atomicAdd(&A.stats[10], (unsigned long long) tk_sched);
     atomicMax(&A.stats[9], (unsigned long long) tk_total);
   }
 }
@@ -473,23 +481,28 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
-  long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_rounds = 0;  // STATS: cycle stamps
+  unsigned long long st_stale = 0;
+  long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_rounds = 0, tk_sched = 0, tk_head = 0, tk_tail = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
   const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
   int part = blockIdx.x & 7, tried = 0;
   for (;;) {  // XCD-aware dynamic chunked scheduling, see next_chunk
   uint32_t chunk = 0;
+  const long long tks = STATS ? clock64() : 0;
   if (!next_chunk(A.work_counter, nchunks, part, tried, lane, chunk)) break;
+  if (STATS) tk_sched += clock64() - tks;
   const uint64_t g_begin = (uint64_t) chunk * A.chunk_groups;
   const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
   for (uint64_t g = g_begin; g < g_end; g++) {
+    const long long tkg = STATS ? clock64() : 0;
     const uint64_t ip = g * 64 + lane;
     const bool valid = ip < A.n;
     int64_t px = 0, py = 0;
     if (valid) {
-      longlong2 p = reinterpret_cast<const longlong2*>(A.pts)[ip];
-      px = p.x; py = p.y;
+      // streamed once: keep it out of the way of the tree levels that live in L2
+      px = __builtin_nontemporal_load(A.pts + 2 * ip);
+      py = __builtin_nontemporal_load(A.pts + 2 * ip + 1);
     }
     const int32_t qx = quant(px), qy = quant(py);
     const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
@@ -563,6 +576,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       sp = n;
       wave_lds_fence();
     }
+    if (STATS) tk_head += clock64() - tkg;
     while (sp > 0) {
       const uint4 ent = L.stack[sp - 1];
       --sp;
@@ -570,7 +584,10 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       const int32_t ey0 = (int32_t) __builtin_amdgcn_readfirstlane(ent.y);
       const uint64_t emask = ((uint64_t) __builtin_amdgcn_readfirstlane(ent.w) << 32) | __builtin_amdgcn_readfirstlane(ent.z);
       // stale?  (every lane that wanted this node has a bound below it by now)
-      if (!__ballot(((emask >> lane) & 1) && ey0 <= qbest)) continue;
+      if (!__ballot(((emask >> lane) & 1) && ey0 <= qbest)) {
+        if (STATS) st_stale++;
+        continue;
+      }
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
       if (lvl > 1) {
@@ -617,9 +634,10 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         if (STATS) tk_leaf += (clock64() - tk0) - (tk_drain - tkd0);
       }
     }
+    const long long tkt = STATS ? clock64() : 0;
     evaluate();
     if (valid) {
-      A.closest[ip] = best_eid;
+      __builtin_nontemporal_store(best_eid, A.closest + ip);
       if (A.face) {
         int32_t f = 0;  // EXTERIOR_FACE_ID
         if (best_eid != 0xFFFFFFFFu) {
@@ -627,9 +645,10 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
           uint32_t c = A.base.edge_chain[best_eid];
           f = (int32_t) (s.x1 < s.x2 ? A.base.right[c] : A.base.left[c]);  // map.h:79-87
         }
-        A.face[ip] = f;
+        __builtin_nontemporal_store(f, A.face + ip);
       }
     }
+    if (STATS) tk_tail += clock64() - tkt;
   }
   }
   if (STATS && lane == 0 && A.stats) {
@@ -644,6 +663,10 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
     atomicAdd(&A.stats[7], (unsigned long long) tk_drain);
     atomicAdd(&A.stats[8], (unsigned long long) tk_rounds);
     atomicMax(&A.stats[9], (unsigned long long) tk_total);
+    atomicAdd(&A.stats[10], (unsigned long long) tk_sched);
+    atomicAdd(&A.stats[11], (unsigned long long) tk_head);
+    atomicAdd(&A.stats[12], (unsigned long long) tk_tail);
+    atomicAdd(&A.stats[13], st_stale);
   }
 }
 
