@@ -128,7 +128,8 @@ typedef enum {
   RJ_T_LSI_KERNEL = 1,/* the LSI traversal+predicate kernel of the last rj_lsi_query* */
   RJ_T_PIP_KERNEL = 2,/* the PIP kernel of the last rj_pip_query* */
   RJ_T_LSI_POINTS = 3,
-  RJ_T_SORT = 4
+  RJ_T_SORT = 4,
+  RJ_T_ORDER = 5      /* Morton re-ordering of an incoherent query set inside the last query, if any */
 } rj_timer;
 /* HIP-event time (ms) of the last launch of that stage on the handle's stream; syncs. */
 int rj_last_ms(rj_handle h, int which, float* ms);
@@ -139,6 +140,10 @@ int rj_last_ms(rj_handle h, int which, float* ms);
  * build (total, node expansion, leaf loop, dense predicate phase, merge rounds, max wave total).
  * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
 int rj_last_stats(rj_handle h, uint64_t stats[16]);
+/* options: "stats" 0/1; "chunk_groups" n; "max_blocks" n; "own_stream" 1;
+ * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
+ * consecutive queries are spatially scattered, e.g. the generated workloads of
+ * src/run_query.cu:102-167) / 2 always. */
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 
 /* ---- device memory helpers (for hosts without their own allocator) -------------------- */

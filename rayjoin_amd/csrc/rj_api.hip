@@ -40,7 +40,10 @@ struct BvhState {
   int top = 0;
 };
 
-constexpr int kNumTimers = 5;
+constexpr int kNumTimers = 6;
+// average (w + h) of a 64-query group's quantised box above which the query set is re-ordered
+// along the Morton curve before the kernels run (the domain is 2^31 wide per axis)
+constexpr unsigned long long kIncoherentExtent = 1ull << 28;
 
 }  // namespace
 
@@ -56,6 +59,14 @@ struct rj_handle_s {
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
+  int query_order = 1;  // 0 never, 1 auto (estimate coherence), 2 always
+  bool last_ordered = false;
+  // grow-only scratch of the query-ordering pass
+  uint64_t ord_cap = 0;
+  uint64_t *ord_kin = nullptr, *ord_kout = nullptr;
+  uint32_t *ord_vin = nullptr, *ord_vout = nullptr;
+  void* ord_temp = nullptr;
+  size_t ord_temp_bytes = 0;
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 4;      // consecutive 64-query groups handed to a wave at a time
   uint64_t last_stats[16] = {0};
@@ -161,6 +172,7 @@ int rj_destroy(rj_handle h) {
   (void) hipStreamSynchronize(h->stream);
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); }
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned);
+  (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
   (void) hipStreamDestroy(h->own_stream);
   delete h;
@@ -187,6 +199,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!name) return fail(h, RJ_E_INVALID, "null option name");
   if (!strcmp(name, "stats")) { h->stats_on = value != 0; return RJ_OK; }
   if (!strcmp(name, "own_stream")) { h->stream = h->own_stream; return RJ_OK; }
+  if (!strcmp(name, "query_order")) {
+    if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "query_order: 0 never, 1 auto, 2 always");
+    h->query_order = (int) value;
+    return RJ_OK;
+  }
   if (!strcmp(name, "chunk_groups")) {
     if (value < 1 || value > 4096) return fail(h, RJ_E_INVALID, "chunk_groups out of range");
     h->chunk_groups = (int) value;
@@ -335,6 +352,48 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   return RJ_OK;
 }
 
+// Decide whether the query set [begin, begin+n) needs re-ordering and, if so, produce the
+// Morton-sorted permutation (indices relative to `begin`) in h->ord_vout.
+static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
+                               uint64_t n, const uint32_t** order_out) {
+  *order_out = nullptr;
+  h->last_ordered = false;
+  if (h->query_order == 0 || n <= 64) return RJ_OK;
+  if (h->query_order == 1) {
+    RJ_HIP(h, hipMemsetAsync(h->d_stats + 14, 0, 16, h->stream));
+    RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_stats + 14));
+    RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_stats + 14, 16, hipMemcpyDeviceToHost, h->stream));
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    const unsigned long long sum = h->h_pinned[20], groups = h->h_pinned[21];
+    if (groups == 0 || sum / groups <= kIncoherentExtent) return RJ_OK;
+  }
+  if (n > h->ord_cap) {
+    (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout);
+    h->ord_kin = h->ord_kout = nullptr; h->ord_vin = h->ord_vout = nullptr; h->ord_cap = 0;
+    if (int r = dev_alloc(h, &h->ord_kin, n)) return r;
+    if (int r = dev_alloc(h, &h->ord_kout, n)) return r;
+    if (int r = dev_alloc(h, &h->ord_vin, n)) return r;
+    if (int r = dev_alloc(h, &h->ord_vout, n)) return r;
+    h->ord_cap = n;
+  }
+  size_t need = 0;
+  RJ_HIP(h, sort_pairs_u64_u32(h->stream, nullptr, need, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
+  if (need > h->ord_temp_bytes) {
+    (void) hipFree(h->ord_temp);
+    h->ord_temp = nullptr; h->ord_temp_bytes = 0;
+    RJ_HIP(h, hipMalloc(&h->ord_temp, need));
+    h->ord_temp_bytes = need;
+  }
+  tic(h, RJ_T_ORDER);
+  RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin));
+  size_t tb = h->ord_temp_bytes;
+  RJ_HIP(h, sort_pairs_u64_u32(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
+  toc(h, RJ_T_ORDER);
+  *order_out = h->ord_vout;
+  h->last_ordered = true;
+  return RJ_OK;
+}
+
 static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
                       uint64_t capacity, uint32_t* pairs_dev) {
   if (base_map_id < 0 || base_map_id > 1 || query_map_id != 1 - base_map_id)
@@ -346,9 +405,12 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 128 + 8 * 128, h->stream));  // Queue::Clear (queue.h:125-129) + scheduler
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
+  const uint32_t* order = nullptr;
+  if (int r = maybe_order_queries(h, false, nullptr, h->map[query_map_id].seg, qb, qe - qb, &order)) return r;
   LsiArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.qseg = h->map[query_map_id].seg;
+  a.order = order;
   a.qbeg = qb; a.qend = qe;
   a.base_is_map0 = base_map_id == 0;
   a.out = pairs_dev; a.cap = capacity;
@@ -442,10 +504,13 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   if (int r = set_device(h)) return r;
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   RJ_HIP(h, hipMemsetAsync(h->d_counter + 16, 0, 8 * 128, h->stream));
+  const uint32_t* order = nullptr;
+  if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order)) return r;
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.base = map_view(h->map[base_map_id]);
   a.pts = pts; a.n = n;
+  a.order = order;
   a.query_map_id = query_map_id;
   a.closest = closest_eid_dev; a.face = face_id_dev;
   a.work_counter = (unsigned int*) (h->d_counter + 16);

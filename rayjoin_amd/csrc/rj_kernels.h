@@ -15,6 +15,7 @@ static_assert(sizeof(Seg) == 32 && sizeof(QBox) == 16, "layout");
 struct LsiArgs {
   DeviceBvh bvh;
   const Seg* qseg;     // query map segments in eid order
+  const uint32_t* order; // nullable: Morton-sorted positions (relative to qbeg) for incoherent query sets
   uint64_t qbeg, qend; // query eid range
   int base_is_map0;
   uint32_t* out;       // pairs out [2*cap]
@@ -29,6 +30,7 @@ struct PipArgs {
   DeviceBvh bvh;
   DeviceMap base;
   const int64_t* pts;  // query points (x,y interleaved), already offset to the first point
+  const uint32_t* order; // nullable: Morton-sorted point indices for incoherent query sets
   uint64_t n;
   int query_map_id;
   uint32_t* closest;   // [n]
@@ -53,6 +55,10 @@ hipError_t launch_mark_occupancy(hipStream_t st, const QBox* box0, uint64_t n0, 
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks);
+hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
+                               uint64_t n, unsigned long long* out2);
+hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
+                             uint64_t n, uint64_t* keys, uint32_t* vals);
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
                              uint64_t n, XsectRec* out);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);

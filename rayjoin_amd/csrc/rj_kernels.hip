@@ -198,6 +198,64 @@ __device__ __forceinline__ int wave_upper_bound(int32_t v, int32_t key) {
   return k;
 }
 
+// =============================================================================================
+// Query-side ordering for spatially incoherent query sets (GenerateLSIQueries/GeneratePIPQueries,
+// run_query.cu:102-167, or any unsorted point array).  A wave works on 64 consecutive queries; if
+// those are scattered over the map the wave serialises 64 unrelated traversals.  k_group_extent
+// samples the average box half-perimeter of such groups; when it is large the host sorts the
+// queries by Morton key once (rocPRIM) and the kernels run through the permutation.
+// =============================================================================================
+// boxes: per query a quantised box (points: x0==x1, y0==y1).  extent_sum += w + h of sampled groups
+template <bool POINTS>
+__global__ __launch_bounds__(256) void k_group_extent(const int64_t* __restrict__ pts, const Seg* __restrict__ segs,
+                                                      uint64_t begin, uint64_t n, uint64_t group_stride,
+                                                      unsigned long long* __restrict__ out /* [2] sum, groups */) {
+  const int lane = lane_id();
+  const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+  const uint64_t ngroups = (n + 63) >> 6;
+  unsigned long long sum = 0, cnt = 0;
+  for (uint64_t g = wave * group_stride; g < ngroups; g += nwaves * group_stride) {
+    const uint64_t i = g * 64 + lane;
+    int32_t x0 = kEmptyMin, y0 = kEmptyMin, x1 = kEmptyMax, y1 = kEmptyMax;
+    if (i < n) {
+      if (POINTS) {
+        x0 = x1 = quant(pts[2 * (begin + i)]);
+        y0 = y1 = quant(pts[2 * (begin + i) + 1]);
+      } else {
+        const Seg s = segs[begin + i];
+        x0 = quant(s.x1 < s.x2 ? s.x1 : s.x2); x1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
+        y0 = quant(s.y1 < s.y2 ? s.y1 : s.y2); y1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+      }
+    }
+    x0 = wave_min(x0); y0 = wave_min(y0); x1 = wave_max(x1); y1 = wave_max(y1);
+    sum += (unsigned long long) (x1 - x0) + (unsigned long long) (y1 - y0);
+    cnt++;
+  }
+  if (lane == 0 && cnt) {
+    atomicAdd(&out[0], sum);
+    atomicAdd(&out[1], cnt);
+  }
+}
+
+template <bool POINTS>
+__global__ __launch_bounds__(256) void k_query_keys(const int64_t* __restrict__ pts, const Seg* __restrict__ segs,
+                                                    uint64_t begin, uint64_t n, uint64_t* __restrict__ keys,
+                                                    uint32_t* __restrict__ vals) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+    int64_t mx, my;
+    if (POINTS) {
+      mx = pts[2 * (begin + i)]; my = pts[2 * (begin + i) + 1];
+    } else {
+      const Seg s = segs[begin + i];
+      mx = (s.x1 + s.x2) >> 1; my = (s.y1 + s.y2) >> 1;
+    }
+    const uint32_t ux = (uint32_t) ((uint64_t) (mx + kCoordOffset) >> 15), uy = (uint32_t) ((uint64_t) (my + kCoordOffset) >> 15);
+    keys[i] = (spread32(uy) << 1) | spread32(ux);
+    vals[i] = (uint32_t) i;  // index relative to `begin`
+  }
+}
+
 // XCD-aware dynamic scheduler.  The chunk range is cut into 8 contiguous parts, one per XCD
 // (blocks b and b+8 share an XCD under the observed round-robin placement -- speed only, never
 // correctness), each with its own counter on its own cache line.  Waves of one XCD therefore
@@ -305,8 +363,9 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
   const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
   for (uint64_t g = g_begin; g < g_end; g++) {
     const long long tkg = STATS ? clock64() : 0;
-    const uint64_t q = A.qbeg + g * 64 + lane;
-    const bool valid = q < A.qend;
+    const uint64_t qi = g * 64 + lane;  // position in the (possibly Morton-sorted) query order
+    const bool valid = qi < nq;
+    const uint64_t q = A.qbeg + (A.order ? (valid ? A.order[qi] : 0) : qi);
     int32_t qx0 = kEmptyMin, qy0 = kEmptyMin, qx1 = kEmptyMax, qy1 = kEmptyMax;
     if (valid) {
       Seg s;  // streamed once
@@ -496,8 +555,9 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
   const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
   for (uint64_t g = g_begin; g < g_end; g++) {
     const long long tkg = STATS ? clock64() : 0;
-    const uint64_t ip = g * 64 + lane;
-    const bool valid = ip < A.n;
+    const uint64_t ipos = g * 64 + lane;  // position in the (possibly Morton-sorted) query order
+    const bool valid = ipos < A.n;
+    const uint64_t ip = A.order ? (valid ? A.order[ipos] : 0) : ipos;
     int64_t px = 0, py = 0;
     if (valid) {
       // streamed once: keep it out of the way of the tree levels that live in L2
@@ -754,6 +814,28 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_bloc
     hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(k_lsi<false>, dim3(grid), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
+                               uint64_t n, unsigned long long* out2) {
+  const uint64_t ngroups = (n + 63) / 64;
+  const uint64_t stride = ngroups > 8192 ? ngroups / 8192 : 1;  // sample <= ~8192 groups
+  const int grid = grid_for((ngroups + stride - 1) / stride, 4, 512);
+  if (points)
+    hipLaunchKernelGGL(k_group_extent<true>, dim3(grid), dim3(256), 0, st, pts, segs, begin, n, stride, out2);
+  else
+    hipLaunchKernelGGL(k_group_extent<false>, dim3(grid), dim3(256), 0, st, pts, segs, begin, n, stride, out2);
+  return hipGetLastError();
+}
+
+hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
+                             uint64_t n, uint64_t* keys, uint32_t* vals) {
+  if (n == 0) return hipSuccess;
+  if (points)
+    hipLaunchKernelGGL(k_query_keys<true>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals);
+  else
+    hipLaunchKernelGGL(k_query_keys<false>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals);
   return hipGetLastError();
 }
 

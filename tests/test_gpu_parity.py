@@ -148,6 +148,31 @@ def test_adversarial_integer_lattice(oracle, seed, span, extreme):
     dctx.close()
 
 
+def test_query_ordering_modes_agree(oracle, lattice_pair):
+    """Incoherent query sets are re-ordered along the Morton curve inside the query
+    (rj_set_option "query_order"); never / auto / always must give identical results."""
+    ctx, dctx = lattice_pair
+    h = dctx.handle
+    rng = np.random.default_rng(17)
+    pts = ctx.maps[1].pts[rng.permutation(ctx.maps[1].n_points)]  # shuffled vertices
+    want = oracle.pip_brute(_omap(oracle, ctx.maps[0]), 1, pts)
+    got = {}
+    for mode in (0, 1, 2):
+        h.set_option("query_order", mode)
+        pip = ops.PIPLBVH(dctx)
+        pip.Init(len(pts))
+        pip.Query(1, query_points=pts)
+        got[mode] = (pip.get_closest_eids(), pip.get_face_ids())
+        assert np.array_equal(got[mode][0], want), mode
+        lsi = _lsi(dctx, 1, 100000)
+        got[mode] += (lsi.get_pairs(),)
+    h.set_option("query_order", 1)
+    for mode in (1, 2):
+        for a, b in zip(got[0], got[mode]):
+            assert np.array_equal(a, b)
+    assert h.last_ms(_capi.RJ_T_ORDER) > 0  # the always-mode ran the ordering pass
+
+
 def test_adversarial_chains_face_ids(oracle):
     pa = synth.adversarial_chains(60, 9, 12, 21)
     pb = synth.adversarial_chains(80, 5, 12, 22)
