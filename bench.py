@@ -10,8 +10,12 @@ not obtainable).  Inputs are resident in HBM before the timed region.  Index bui
 separately and reported, never part of `value`.
 
 N>1 (torchrun, one rank per GPU): the query map is sharded by contiguous chain ranges balanced
-by edge count, the base map + LBVH are replicated, and each step ends with an RCCL all-gather
-of the per-rank result queues (LSI pairs, PIP eids).  Total work is fixed: "strong" scaling.
+by edge count, the base map + LBVH are replicated.  The one real exchange of a step is the RCCL
+all-gather-v of the intersection queues (every rank needs the pairs that touch ITS edges of either
+map).  PIP results are per-vertex properties of the query map's chains and are consumed by the
+owner of that chain range (the overlay uses them per edge of the same map,
+src/app/map_overlay_lbvh.h:215-236), so by default they stay sharded; --gather-pip adds the
+119 MB all-gather of closest-eid queues to every step.  Total work is fixed: "strong" scaling.
 
 Prints ONE JSON line on rank 0.
 """
@@ -41,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0)
     ap.add_argument("--check", action="store_true", help="size-independent result checks after timing")
+    ap.add_argument("--gather-pip", action="store_true", help="N>1: also all-gather the PIP result queues every step")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0, collectives over gloo")
     return ap.parse_args()
 
 
@@ -97,11 +104,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from rayjoin_amd import _capi, maps, synth
 
@@ -148,7 +160,7 @@ def main():
         h.pip_query(0, 1, None, p0, p1 - p0, closest, faces)
         if record:
             pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
-        if world > 1:  # RCCL all-gather of the PIP result queues (contiguous point shards)
+        if world > 1 and args.gather_pip:  # optional: all-gather of the PIP result queues
             state["ids_all"] = rjd.allgather_point_results(closest, p1 - p0, max_pts)
         state["n"] = n
 
@@ -209,7 +221,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "int128+f64", "data": "synthetic",
             "config": {"workload": "%s(base, %d segs) |><| %s(query, %d segs, %d points), -query=lsi then -query=pip, "
                                    "-mode=lbvh (software LBVH)" % (args.base, n_r, args.query, n_s, n_p),
-                       "sharding": "query map by chain range x%d, base+LBVH replicated, RCCL all-gather of result queues" % world
+                       "sharding": ("query map by chain range x%d, base+LBVH replicated, RCCL all-gather-v of LSI pairs%s"
+                                    % (world, " and PIP eids" if args.gather_pip else "; PIP results stay with their shard"))
                                    if world > 1 else "single GPU",
                        "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),

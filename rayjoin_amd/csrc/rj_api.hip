@@ -61,6 +61,8 @@ struct rj_handle_s {
   bool stats_on = false;
   int query_order = 1;  // 0 never, 1 auto (estimate coherence), 2 always
   bool last_ordered = false;
+  // coherence decisions for map-owned query sets (immutable after upload): [kind 0=segs,1=points][map]
+  struct CohCache { bool valid = false; uint64_t begin = 0, n = 0; bool incoherent = false; } coh[2][2];
   // grow-only scratch of the query-ordering pass
   uint64_t ord_cap = 0;
   uint64_t *ord_kin = nullptr, *ord_kout = nullptr;
@@ -235,6 +237,7 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   MapState& m = h->map[map_id];
   free_map(m);
   free_bvh(h->bvh[map_id]);
+  h->coh[0][map_id].valid = h->coh[1][map_id].valid = false;
   m.np = np; m.nc = nc; m.ne = np - nc;
   if (int r = dev_alloc(h, &m.pts, 2 * np + 2)) return r;
   if (int r = dev_alloc(h, &m.seg, m.ne)) return r;
@@ -355,17 +358,26 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
 // Decide whether the query set [begin, begin+n) needs re-ordering and, if so, produce the
 // Morton-sorted permutation (indices relative to `begin`) in h->ord_vout.
 static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
-                               uint64_t n, const uint32_t** order_out) {
+                               uint64_t n, const uint32_t** order_out, int owner_map /* -1: caller's array */,
+                               uint64_t key_begin) {
   *order_out = nullptr;
   h->last_ordered = false;
   if (h->query_order == 0 || n <= 64) return RJ_OK;
   if (h->query_order == 1) {
-    RJ_HIP(h, hipMemsetAsync(h->d_stats + 14, 0, 16, h->stream));
-    RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_stats + 14));
-    RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_stats + 14, 16, hipMemcpyDeviceToHost, h->stream));
-    RJ_HIP(h, hipStreamSynchronize(h->stream));
-    const unsigned long long sum = h->h_pinned[20], groups = h->h_pinned[21];
-    if (groups == 0 || sum / groups <= kIncoherentExtent) return RJ_OK;
+    rj_handle_s::CohCache* cc = owner_map >= 0 ? &h->coh[points ? 1 : 0][owner_map] : nullptr;
+    bool incoherent;
+    if (cc && cc->valid && cc->begin == key_begin && cc->n == n) {
+      incoherent = cc->incoherent;  // same immutable range as last time: no estimate, no sync
+    } else {
+      RJ_HIP(h, hipMemsetAsync(h->d_stats + 14, 0, 16, h->stream));
+      RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_stats + 14));
+      RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_stats + 14, 16, hipMemcpyDeviceToHost, h->stream));
+      RJ_HIP(h, hipStreamSynchronize(h->stream));
+      const unsigned long long sum = h->h_pinned[20], groups = h->h_pinned[21];
+      incoherent = groups != 0 && sum / groups > kIncoherentExtent;
+      if (cc) { cc->valid = true; cc->begin = key_begin; cc->n = n; cc->incoherent = incoherent; }
+    }
+    if (!incoherent) return RJ_OK;
   }
   if (n > h->ord_cap) {
     (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout);
@@ -406,7 +418,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 128 + 8 * 128, h->stream));  // Queue::Clear (queue.h:125-129) + scheduler
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   const uint32_t* order = nullptr;
-  if (int r = maybe_order_queries(h, false, nullptr, h->map[query_map_id].seg, qb, qe - qb, &order)) return r;
+  if (int r = maybe_order_queries(h, false, nullptr, h->map[query_map_id].seg, qb, qe - qb, &order, query_map_id, qb)) return r;
   LsiArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.qseg = h->map[query_map_id].seg;
@@ -496,7 +508,9 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   if (!h->bvh[base_map_id].built) return fail(h, RJ_E_INVALID, "rj_pip_query: call rj_build_lbvh(base map) first");
   if (n && !closest_eid_dev) return fail(h, RJ_E_INVALID, "rj_pip_query: null output");
   const int64_t* pts = pts_dev;
+  uint64_t coh_begin = 0;
   if (!pts) {
+    coh_begin = pt_begin;
     const MapState& q = h->map[query_map_id];
     if (!q.present || pt_begin + n > q.np) return fail(h, RJ_E_INVALID, "rj_pip_query: bad point range of the query map");
     pts = q.pts + 2 * pt_begin;
@@ -505,7 +519,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   RJ_HIP(h, hipMemsetAsync(h->d_counter + 16, 0, 8 * 128, h->stream));
   const uint32_t* order = nullptr;
-  if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order)) return r;
+  if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.base = map_view(h->map[base_map_id]);

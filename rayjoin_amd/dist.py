@@ -12,6 +12,21 @@ import torch
 import torch.distributed as dist
 
 
+def _needs_host_staging(t):
+    """gloo has no GPU transport: stage device tensors through the host (CPU rehearsal of the
+    N>1 path on a box with fewer GPUs than ranks).  With nccl (= RCCL) tensors stay on the GPU."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _all_gather_flat(out, inp):
+    if _needs_host_staging(inp):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp)
+
+
 def shard_of(query_map, world, rank):
     """-> dict(chains=(c0,c1), eids=(e0,e1), points=(p0,p1)) of this rank's shard."""
     c0, c1 = query_map.shard_chain_ranges(world)[rank]
@@ -24,7 +39,7 @@ def allgather_counts(n, device):
     world = dist.get_world_size()
     me = torch.tensor([int(n)], dtype=torch.int64, device=device)
     out = torch.empty(world, dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, me)
+    _all_gather_flat(out, me)
     return out
 
 
@@ -44,7 +59,7 @@ def allgather_pairs(pairs, n, scratch=None):
         flat = scratch[:world * gmax * 2]
     else:
         flat = torch.empty(world * gmax * 2, dtype=pairs.dtype, device=pairs.device)
-    dist.all_gather_into_tensor(flat, pairs[:gmax].reshape(-1))  # flat in, flat out: nccl and gloo
+    _all_gather_flat(flat, pairs[:gmax].reshape(-1))  # flat in, flat out: nccl and gloo
     recv = flat.view(world, gmax, 2)
     out = torch.cat([recv[r, :cl[r]] for r in range(world)], dim=0)
     return out, counts
@@ -58,7 +73,7 @@ def allgather_point_results(ids, n, max_n):
     pad = torch.zeros(max_n, dtype=ids.dtype, device=ids.device)
     pad[:n] = ids[:n]
     flat = torch.empty(world * max_n, dtype=ids.dtype, device=ids.device)
-    dist.all_gather_into_tensor(flat, pad)
+    _all_gather_flat(flat, pad)
     recv = flat.view(world, max_n)
     counts = allgather_counts(n, ids.device).tolist()
     return torch.cat([recv[r, :counts[r]] for r in range(world)], dim=0)
