@@ -31,6 +31,7 @@ struct BvhState {
   uint64_t n0 = 0, n0p = 0;
   Seg* sseg = nullptr;
   uint32_t* seid = nullptr;
+  int32_t* sface = nullptr;
   QBox* box0 = nullptr;
   int32_t* pmx1 = nullptr;
   uint32_t* occ = nullptr;
@@ -111,14 +112,14 @@ void free_map(MapState& m) {
 }
 
 void free_bvh(BvhState& b) {
-  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.occ);
+  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.occ);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
 
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
-  d.sseg = b.sseg; d.seid = b.seid; d.box0 = b.box0; d.pmx1 = b.pmx1; d.occ = b.occ;
+  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.occ = b.occ;
   for (int l = 0; l < kMaxLevels; l++) { d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l]; }
   d.top = b.top; d.n0 = b.n0;
   return d;
@@ -310,6 +311,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   b.top = top;
   if (int r = dev_alloc(h, &b.sseg, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.seid, b.n0p)) return r;
+  if (int r = dev_alloc(h, &b.sface, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.box0, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.pmx1, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords)) return r;
@@ -333,10 +335,10 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1)) != hipSuccess) break;
       if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
     }
-    if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.ne, b.n0p, b.sseg, b.seid, b.box0)) != hipSuccess) break;
+    if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p, b.sseg, b.seid, b.sface, b.box0)) != hipSuccess) break;
     if ((e = hipMemsetAsync(b.occ, 0, (size_t) kOccDim * kOccRowWords * 4, h->stream)) != hipSuccess) break;
     if ((e = launch_mark_occupancy(h->stream, b.box0, b.n0p, b.occ)) != hipSuccess) break;
-    if ((e = launch_sort_leaf_blocks(h->stream, b.sseg, b.seid, b.box0, b.pmx1, b.n0p / 64)) != hipSuccess) break;
+    if ((e = launch_sort_leaf_blocks(h->stream, b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.n0p / 64)) != hipSuccess) break;
     const QBox* child = b.box0;
     uint64_t child_alloc = b.n0p;
     for (int l = 1; l <= top; l++) {

@@ -47,6 +47,7 @@ struct DeviceMap {
 struct DeviceBvh {
   const Seg* sseg;        // [n0p] segments in Morton order (padding = zero segments)
   const uint32_t* seid;   // [n0p] original eid of each sorted slot
+  const int32_t* sface;   // [n0p] face below each segment (get_face_id, src/map/map.h:79-87)
   const QBox* box0;       // [n0p] per-segment boxes (padding = empty); sorted by x0 inside each 64-block
   const int32_t* pmx1;    // [n0p] prefix max of box x1 inside each 64-block
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)

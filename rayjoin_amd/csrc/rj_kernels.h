@@ -48,9 +48,10 @@ hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, co
 hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
                          uint64_t* kout, uint64_t n);
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
-hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, uint64_t ne,
-                                uint64_t n0p, Seg* sseg, uint32_t* seid, QBox* box0);
-hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, QBox* box0, int32_t* pmx1, uint64_t nblocks);
+hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
+                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t n0p, Seg* sseg,
+                                uint32_t* seid, int32_t* sface, QBox* box0);
+hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0, int32_t* pmx1, uint64_t nblocks);
 hipError_t launch_mark_occupancy(hipStream_t st, const QBox* box0, uint64_t n0, uint32_t* occ);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);

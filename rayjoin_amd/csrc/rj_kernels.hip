@@ -65,18 +65,25 @@ __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uin
 
 __global__ __launch_bounds__(256) void k_gather_sorted(const Seg* __restrict__ seg,
                                                        const uint32_t* __restrict__ order,
+                                                       const uint32_t* __restrict__ edge_chain,
+                                                       const uint32_t* __restrict__ left,
+                                                       const uint32_t* __restrict__ right,
                                                        uint64_t ne, uint64_t n0p,
                                                        Seg* __restrict__ sseg,
                                                        uint32_t* __restrict__ seid,
+                                                       int32_t* __restrict__ sface,
                                                        QBox* __restrict__ box0) {
   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n0p;
        i += (uint64_t) gridDim.x * blockDim.x) {
     Seg s = {0, 0, 0, 0};
     QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
     uint32_t id = 0xFFFFFFFFu;
+    int32_t face = 0;
     if (i < ne) {
       id = order[i];
       s = seg[id];
+      const uint32_t c = edge_chain[id];
+      face = (int32_t) (s.x1 < s.x2 ? right[c] : left[c]);  // get_face_id, map.h:79-87
       b.x0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
       b.x1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
       b.y0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(256) void k_gather_sorted(const Seg* __restrict__ s
     }
     sseg[i] = s;
     seid[i] = id;
+    sface[i] = face;
     box0[i] = b;
   }
 }
@@ -130,8 +138,8 @@ __device__ __forceinline__ bool occ_any(const uint32_t* __restrict__ occ, int32_
 // a backward scan that stops as soon as pmx1 drops below the query's x -- one or two steps for
 // an x-monotone run of a polyline instead of a 64-iteration uniform loop.
 __global__ __launch_bounds__(256) void k_sort_leaf_blocks(Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
-                                                          QBox* __restrict__ box0, int32_t* __restrict__ pmx1,
-                                                          uint64_t nblocks) {
+                                                          int32_t* __restrict__ sface, QBox* __restrict__ box0,
+                                                          int32_t* __restrict__ pmx1, uint64_t nblocks) {
   __shared__ int32_t sx1[4][64];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void k_sort_leaf_blocks(Seg* __restrict__ sseg
     const uint64_t i = blk * 64 + lane;
     const Seg s = sseg[i];
     const uint32_t id = seid[i];
+    const int32_t fc = sface[i];
     const QBox b = box0[i];
     int rank = 0;
     for (int k = 0; k < 64; k++) {
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(256) void k_sort_leaf_blocks(Seg* __restrict__ sseg
     const uint64_t o = blk * 64 + rank;
     sseg[o] = s;
     seid[o] = id;
+    sface[o] = fc;
     box0[o] = b;
     sx1[wib][rank] = b.x1;
     wave_lds_fence();
@@ -185,16 +195,22 @@ __global__ __launch_bounds__(256) void k_reduce_level(const QBox* __restrict__ c
 }
 
 
-// number of lanes j with v[j] <= key, for v non-decreasing over the 64 lanes (lane j holds v[j])
+// number of lanes j with v[j] <= key, for v non-decreasing over the 64 lanes (lane j holds v[j]).
+// Two stages: 7 wave-uniform pivots (v at lanes 7, 15, ... 55; v_readlane -> SGPR, no latency chain)
+// pick the 8-lane bucket, then 3 dependent cross-lane probes + 1 finish inside it -- instead of 7
+// dependent ds_bpermute round trips.
 __device__ __forceinline__ int wave_upper_bound(int32_t v, int32_t key) {
   int k = 0;
 #pragma unroll
-  for (int step = 32; step >= 1; step >>= 1) {
+  for (int p = 7; p < 63; p += 8) k += (bcast(v, p) <= key) ? 8 : 0;  // v[p] <= key => lanes 0..p all count
+  // now the answer lies in [k, k + 8]; v[k-1] <= key (or k == 0)
+#pragma unroll
+  for (int step = 4; step >= 1; step >>= 1) {
     const int32_t probe = __shfl(v, k + step - 1, 64);
     if (probe <= key) k += step;
   }
-  const int32_t last = __shfl(v, k, 64);  // k <= 63
-  if (last <= key) k++;
+  const int32_t last = __shfl(v, k < 63 ? k : 63, 64);
+  if (k < 64 && last <= key) k++;
   return k;
 }
 
@@ -569,31 +585,42 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
     const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
     const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
     double best_yy = __builtin_inf(), best_slope = 0.0;
-    uint32_t best_eid = 0xFFFFFFFFu;
+    uint32_t best_slot = 0xFFFFFFFFu;  // sorted slot of the best edge so far (eid/face are looked up at the end)
     int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer
     int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
     int cnt = 0;                              // this lane's candidate-list fill
+    bool sure1 = false;  // the list holds exactly one candidate and it is a certain hit
 
     // every lane evaluates its own candidate list exactly (pip.h:36-95), then clears it
-    auto evaluate = [&]() {
+    auto evaluate = [&](bool final_round) {
       const long long tk0 = STATS ? clock64() : 0;
+      // A lane whose ONLY candidate of the whole traversal is a certain hit needs no arithmetic:
+      // every other edge over this x was pruned because it starts above that candidate's box top,
+      // so the candidate is the answer (the common case for an x-monotone polyline overhead).
+      if (final_round && cnt == 1 && sure1 && best_slot == 0xFFFFFFFFu) {
+        best_slot = L.cand[0][lane];
+        cnt = 0;
+      }
       const int maxc = wave_max(cnt);
       for (int r = 0; r < maxc; r++) {
         if (r < cnt) {
           const uint32_t slot = L.cand[r][lane];
           const Seg bs = T.sseg[slot];
-          const uint32_t eid = T.seid[slot];
           double yy, slope;
-          if (pip_eval(bs, px, py, qm, &yy, &slope) &&
-              pip_better(yy, slope, eid, best_yy, best_slope, best_eid, qm)) {
-            best_yy = yy; best_slope = slope; best_eid = eid;
+          if (pip_eval(bs, px, py, qm, &yy, &slope)) {
+            bool better = yy < best_yy;
+            if (yy == best_yy && best_slot != 0xFFFFFFFFu)  // tie: slope rule, then eid (rare: look the eids up now)
+              better = pip_better(yy, slope, T.seid[slot], best_yy, best_slope, T.seid[best_slot], qm);
+            if (better) {
+              best_yy = yy; best_slope = slope; best_slot = slot;
+            }
           }
         }
         if (STATS) tk_rounds++;
       }
       if (STATS) st_tests += (unsigned long long) __popcll(__ballot(cnt > 0));
       cnt = 0;
-      if (best_eid != 0xFFFFFFFFu) {
+      if (best_slot != 0xFFFFFFFFu && best_yy < __builtin_inf()) {
         // exact best known: tighten the integer bound (conservative: +1 quantum)
         double t = (best_yy + (double) kCoordOffset) * (1.0 / 65536.0);
         int32_t qb = t < 2147483000.0 ? (t < -1.0 ? -1 : (int32_t) t + 1) : 0x7FFFFFFF;
@@ -682,12 +709,14 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
           const int32_t sy0 = __shfl(bb.y0, jj, 64), sy1 = __shfl(bb.y1, jj, 64);
           if (act && sx1 >= qx && sy1 >= qy - 1 && sy0 <= qbest) {
             L.cand[cnt][lane] = slot0 + (uint32_t) jj;
-            cnt++;
             // certain hit (strictly inside in x, strictly above) => its box top bounds the answer
-            if (sx0 < qx && qx < sx1 && sy0 > qy && sy1 < qbest - 1) qbest = sy1 + 1;
+            const bool certain = sx0 < qx && qx < sx1 && sy0 > qy;
+            sure1 = cnt == 0 && certain;
+            cnt++;
+            if (certain && sy1 < qbest - 1) qbest = sy1 + 1;
           }
           if (STATS) st_box++;
-          if (__ballot(cnt >= kPipList)) evaluate();
+          if (__ballot(cnt >= kPipList)) evaluate(false);
           j--;
         }
         gbest = wave_max(qbest);
@@ -695,18 +724,12 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       }
     }
     const long long tkt = STATS ? clock64() : 0;
-    evaluate();
+    evaluate(true);
     if (valid) {
-      __builtin_nontemporal_store(best_eid, A.closest + ip);
-      if (A.face) {
-        int32_t f = 0;  // EXTERIOR_FACE_ID
-        if (best_eid != 0xFFFFFFFFu) {
-          Seg s = A.base.seg[best_eid];
-          uint32_t c = A.base.edge_chain[best_eid];
-          f = (int32_t) (s.x1 < s.x2 ? A.base.right[c] : A.base.left[c]);  // map.h:79-87
-        }
-        __builtin_nontemporal_store(f, A.face + ip);
-      }
+      const bool hit = best_slot != 0xFFFFFFFFu;
+      __builtin_nontemporal_store(hit ? T.seid[best_slot] : 0xFFFFFFFFu, A.closest + ip);
+      // face below the hit edge (precomputed per sorted slot at build time), EXTERIOR_FACE_ID on a miss
+      if (A.face) __builtin_nontemporal_store(hit ? T.sface[best_slot] : 0, A.face + ip);
     }
     if (STATS) tk_tail += clock64() - tkt;
   }
@@ -770,15 +793,16 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {
   return hipGetLastError();
 }
 
-hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, uint64_t ne,
-                                uint64_t n0p, Seg* sseg, uint32_t* seid, QBox* box0) {
-  hipLaunchKernelGGL(k_gather_sorted, dim3(grid_for(n0p, 256, 8192)), dim3(256), 0, st, seg, order,
-                     ne, n0p, sseg, seid, box0);
+hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
+                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t n0p, Seg* sseg,
+                                uint32_t* seid, int32_t* sface, QBox* box0) {
+  hipLaunchKernelGGL(k_gather_sorted, dim3(grid_for(n0p, 256, 8192)), dim3(256), 0, st, seg, order, edge_chain,
+                     left, right, ne, n0p, sseg, seid, sface, box0);
   return hipGetLastError();
 }
 
-hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, QBox* box0, int32_t* pmx1, uint64_t nblocks) {
-  hipLaunchKernelGGL(k_sort_leaf_blocks, dim3(grid_for(nblocks, 4, 8192)), dim3(256), 0, st, sseg, seid, box0, pmx1, nblocks);
+hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0, int32_t* pmx1, uint64_t nblocks) {
+  hipLaunchKernelGGL(k_sort_leaf_blocks, dim3(grid_for(nblocks, 4, 8192)), dim3(256), 0, st, sseg, seid, sface, box0, pmx1, nblocks);
   return hipGetLastError();
 }
 
