@@ -1,0 +1,71 @@
+"""BASELINE.json configs[1] at FULL size (USCounty x BlockGroup stand-ins, 7.1 M x 28.8 M
+segments): bit-exact parity with the CPU grid oracle (it finishes in seconds on the GPU box's
+cores) plus the size-independent properties the domain offers."""
+import numpy as np
+import pytest
+import torch
+
+from rayjoin_amd import _capi, maps, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_uscounty_blockgroup_full_size(oracle):
+    oracle.lib().rjo_set_num_threads(16)  # the box's CPU share for one GPU
+    ctx = maps.Context([synth.standin("USCounty"), synth.standin("BlockGroup")]).load()
+    base, query = ctx.maps
+    h = _capi.Handle(0)
+    h.upload_map(0, base.pts, base.row_index, base.left, base.right)
+    h.upload_map(1, query.pts, query.row_index, query.left, query.right)
+    h.build_lbvh(0)
+    cap = int(0.1 * (base.n_edges + query.n_edges))
+    pairs = h.alloc(8 * cap)
+    n = h.lsi_query(0, 1, 0, query.n_edges, cap, pairs)
+    h.sort_pairs(pairs, n)
+    got = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
+    key = (got[:, 0].astype(np.uint64) << np.uint64(32)) | got[:, 1]
+    assert (key[1:] > key[:-1]).all()  # sorted, no duplicates
+    xs_dev = h.alloc(48 * n)
+    h.lsi_points(pairs, n, xs_dev)
+    xs = xs_dev.to_host(_capi.XSECT_DTYPE, n)
+    closest = h.alloc(4 * query.n_points)
+    faces = h.alloc(4 * query.n_points)
+    h.pip_query(0, 1, None, 0, query.n_points, closest, faces)
+    eids = closest.to_host(np.uint32)
+    fids = faces.to_host(np.int32)
+
+    # --- bit-exact against the oracle's -mode=grid at full size
+    m0 = oracle.Map(base.pts, base.row_index, base.left, base.right)
+    m1 = oracle.Map(query.pts, query.row_index, query.left, query.right)
+    want = oracle.lsi_grid(m0, m1, 2048, cap=cap)
+    assert len(want) == n > 100000
+    assert np.array_equal(want["eid"], got)
+    assert np.array_equal(want["x_num"], xs["x_num"]) and np.array_equal(want["y_num"], xs["y_num"])
+    we = oracle.pip_grid(m0, 0, query.pts, 2048)
+    assert np.array_equal(we, eids)
+    assert np.array_equal(m0.face_ids(we), fids)
+    del m1, want
+
+    # --- role symmetry: index the other map; the predicate order is fixed, so the set is identical
+    h.build_lbvh(1)
+    p2 = h.alloc(8 * cap)
+    n2 = h.lsi_query(1, 0, 0, base.n_edges, cap, p2)
+    h.sort_pairs(p2, n2)
+    assert n2 == n and np.array_equal(p2.to_host(np.uint32, 2 * n2).reshape(-1, 2), got)
+    # --- shard additivity over 8 chain-range shards
+    parts = []
+    for c0, c1 in query.shard_chain_ranges(8):
+        e0, e1 = query.chain_range_to_eids(c0, c1)
+        k = h.lsi_query(0, 1, e0, e1, cap, p2)
+        parts.append(p2.to_host(np.uint32, 2 * k).reshape(-1, 2))
+    allp = oracle.sort_pairs(np.concatenate(parts))
+    assert np.array_equal(allp, got)
+    # --- PIP permutation invariance (also exercises the Morton re-ordering of a shuffled set)
+    m = 1 << 21
+    perm = np.random.default_rng(3).permutation(m)
+    d = h.alloc(16 * m).from_host(query.pts[:m][perm])
+    c = h.alloc(4 * m)
+    h.pip_query(0, 1, d, 0, m, c, None)
+    assert np.array_equal(c.to_host(np.uint32), eids[:m][perm])
+    assert h.last_ms(_capi.RJ_T_ORDER) > 0
+    h.close()
