@@ -122,6 +122,18 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
                        uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev,
                        int32_t* face_id_dev);
 
+/* ---- overlay support ------------------------------------------------------------------- */
+/* replaces: the per-map body of MapOverlayLBVH::ComputeOutputPolygons
+ * (src/app/map_overlay_lbvh.h:109-265).  For map `im`: the n intersections (eid map 0, eid map 1)
+ * become 48-byte records ordered by eid[im] and, on one edge, by squared distance of the stored
+ * point from that edge's first endpoint (:204-213; the reference's unstable ties are resolved by
+ * the other map's eid); the mid-point of each consecutive pair on an edge (:215-227) is located
+ * in the other map (query map id = im, :232-236) and the face found is stored in the FIRST record
+ * of the pair (mid_point_polygon_id, :238-262); the last record of an edge keeps DONTKNOW (-1).
+ * Needs rj_build_lbvh(1 - im).  xsects_dev[n] is caller-owned device memory. */
+int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint64_t n,
+                           rj_xsect* xsects_dev);
+
 /* ---- measurement ---------------------------------------------------------------------- */
 typedef enum {
   RJ_T_BUILD = 0,     /* whole rj_build_lbvh */

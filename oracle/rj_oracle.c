@@ -688,6 +688,73 @@ void rjo_pip_grid(const rjo_map* base, int base_map_id, const rjo_grid* gr, cons
   }
 }
 
+
+/* ------------------------------------------------------------------------------------------
+ * Overlay: per-map ordering of intersections + mid-point faces
+ * -- src/app/map_overlay_lbvh.h:109-265 (ComputeOutputPolygons), same steps in
+ *    src/app/map_overlay_grid.h.  Deterministic restatement: the reference's thrust::sort calls
+ *    are unstable; ties (same edge, same squared distance) are ordered by the other map's eid.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  rjo_xsect x;
+  u128 d2;
+  uint32_t mine, other;
+} ovl_rec;
+
+static int ovl_cmp(const void* a, const void* b) {
+  const ovl_rec *p = (const ovl_rec*) a, *q = (const ovl_rec*) b;
+  if (p->mine != q->mine) return p->mine < q->mine ? -1 : 1;
+  if (p->d2 != q->d2) return p->d2 < q->d2 ? -1 : 1; /* :204-213 */
+  if (p->other != q->other) return p->other < q->other ? -1 : 1;
+  return 0;
+}
+
+/* pairs = n (eid map 0, eid map 1); out = n records ordered for map `im`; gsize = grid for the
+ * mid-point PIP (results do not depend on it) */
+void rjo_overlay_edge_xsects(const rjo_map* m0, const rjo_map* m1, int im, const uint32_t* pairs,
+                             uint64_t n, int gsize, rjo_xsect* out) {
+  if (n == 0) return;
+  const rjo_map* mine = im ? m1 : m0;
+  const rjo_map* base = im ? m0 : m1;
+  ovl_rec* r = (ovl_rec*) malloc(sizeof(ovl_rec) * n);
+  rjo_lsi_points(m0, m1, pairs, n, out);
+  for (uint64_t i = 0; i < n; i++) {
+    r[i].x = out[i];
+    r[i].x.mid_point_polygon_id = -1;
+    r[i].mine = out[i].eid[im];
+    r[i].other = out[i].eid[1 - im];
+    rjo_pt p1 = mine->pts[mine->edges[r[i].mine].p1];
+    i128 dx = (i128) out[i].x_num - p1.x, dy = (i128) out[i].y_num - p1.y;
+    r[i].d2 = (u128) (dx * dx) + (u128) (dy * dy);
+  }
+  qsort(r, n, sizeof(ovl_rec), ovl_cmp);
+  /* mid-points of consecutive intersections on one edge (:215-227):
+   * x1 + (x2 - x1)/2 as a rational, stored through operator double -> trunc((x1 + x2)/2) */
+  int64_t* mid = (int64_t*) malloc(16 * n);
+  for (uint64_t i = 0; i < n; i++) {
+    int64_t mx = r[i].x.x_num, my = r[i].x.y_num;
+    if (i + 1 < n && r[i + 1].mine == r[i].mine) {
+      rat128 x = rat_make((i128) r[i].x.x_num + r[i + 1].x.x_num, 2);
+      rat128 y = rat_make((i128) r[i].x.y_num + r[i + 1].x.y_num, 2);
+      mx = (int64_t) rat_to_double(x);
+      my = (int64_t) rat_to_double(y);
+    }
+    mid[2 * i] = mx;
+    mid[2 * i + 1] = my;
+  }
+  uint32_t* eids = (uint32_t*) malloc(4 * n);
+  rjo_grid* g = rjo_grid_build(im ? base : NULL, im ? NULL : base, gsize); /* base map id = 1 - im */
+  rjo_pip_grid(base, 1 - im, g, mid, n, eids);                             /* query map id = im (:232-236) */
+  rjo_grid_free(g);
+  for (uint64_t i = 0; i < n; i++) {
+    if (i + 1 < n && r[i + 1].mine == r[i].mine) r[i].x.mid_point_polygon_id = face_id_of(base, eids[i]);
+    out[i] = r[i].x;
+  }
+  free(eids);
+  free(mid);
+  free(r);
+}
+
 int rjo_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

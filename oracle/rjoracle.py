@@ -79,6 +79,7 @@ def lib():
     L.rjo_lsi_grid.restype = C.c_uint64
     L.rjo_lsi_grid.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.rjo_pip_grid.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _i64p, C.c_size_t, _u32p]
+    L.rjo_overlay_edge_xsects.argtypes = [C.c_void_p, C.c_void_p, C.c_int, _u32p, C.c_uint64, C.c_int, C.c_void_p]
     L.rjo_num_threads.restype = C.c_int
     L.rjo_set_num_threads.argtypes = [C.c_int]
     _lib = L
@@ -207,6 +208,14 @@ def lsi_points(m0, m1, pairs):
     pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
     out = np.zeros(pairs.shape[0], dtype=XSECT_DTYPE)
     lib().rjo_lsi_points(m0.h, m1.h, pairs.reshape(-1), pairs.shape[0], out.ctypes.data)
+    return out
+
+
+def overlay_edge_xsects(m0, m1, im, pairs, gsize=2048):
+    """Intersection records ordered for map `im` with mid-point faces (ComputeOutputPolygons)."""
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32).reshape(-1, 2)
+    out = np.zeros(pairs.shape[0], dtype=XSECT_DTYPE)
+    lib().rjo_overlay_edge_xsects(m0.h, m1.h, im, pairs.reshape(-1), pairs.shape[0], gsize, out.ctypes.data)
     return out
 
 

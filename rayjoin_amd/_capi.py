@@ -38,6 +38,7 @@ SYMBOLS = {
     "rj_lsi_query_finish": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "rj_lsi_points": (_int, [_vp, _vp, _u64, _vp]),
     "rj_sort_pairs": (_int, [_vp, _vp, _u64]),
+    "rj_overlay_edge_xsects": (_int, [_vp, _int, _vp, _u64, _vp]),
     "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_last_ms": (_int, [_vp, _int, C.POINTER(C.c_float)]),
@@ -220,6 +221,9 @@ class Handle:
 
     def lsi_points(self, pairs_dev, n, out_dev):
         self._check(self.L.rj_lsi_points(self.h, _ptr(pairs_dev), n, _ptr(out_dev)))
+
+    def overlay_edge_xsects(self, im, pairs_dev, n, xsects_dev):
+        self._check(self.L.rj_overlay_edge_xsects(self.h, im, _ptr(pairs_dev), n, _ptr(xsects_dev)))
 
     def sort_pairs(self, pairs_dev, n):
         self._check(self.L.rj_sort_pairs(self.h, _ptr(pairs_dev), n))

@@ -548,6 +548,54 @@ int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* 
   return RJ_OK;
 }
 
+
+int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint64_t n, rj_xsect* xsects_dev) {
+  RJ_CHECK_H(h);
+  if (im < 0 || im > 1) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: im must be 0 or 1");
+  if (!h->map[0].present || !h->map[1].present) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: both maps must be uploaded");
+  if (!h->bvh[1 - im].built) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: call rj_build_lbvh(%d) first (mid-points are located in the other map)", 1 - im);
+  if (n && (!pairs_dev || !xsects_dev)) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: null buffer");
+  if (n == 0) return RJ_OK;
+  if (n >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: too many intersections");
+  if (int r = set_device(h)) return r;
+  XsectRec* tmp = nullptr;
+  uint64_t *kin = nullptr, *kout = nullptr;
+  uint32_t *vin = nullptr, *vout = nullptr, *closest = nullptr;
+  int32_t* face = nullptr;
+  int64_t* mid = nullptr;
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  int rc = RJ_OK;
+  hipError_t e = hipSuccess;
+  do {
+    if ((rc = dev_alloc(h, &tmp, n))) break;
+    if ((rc = dev_alloc(h, &kin, n))) break;
+    if ((rc = dev_alloc(h, &kout, n))) break;
+    if ((rc = dev_alloc(h, &vin, n))) break;
+    if ((rc = dev_alloc(h, &vout, n))) break;
+    if ((rc = dev_alloc(h, &closest, n))) break;
+    if ((rc = dev_alloc(h, &face, n))) break;
+    if ((rc = dev_alloc(h, &mid, 2 * n))) break;
+    // 1. the 48-byte records  2. order by (eid[im], eid[1-im])  3. per-edge order by distance, mid-points
+    if ((e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, tmp)) != hipSuccess) break;
+    if ((e = launch_xsect_keys(h->stream, tmp, n, im, kin, vin)) != hipSuccess) break;
+    if ((e = sort_pairs_u64_u32(h->stream, nullptr, temp_bytes, kin, kout, vin, vout, n)) != hipSuccess) break;
+    if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1)) != hipSuccess) break;
+    if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, kin, kout, vin, vout, n)) != hipSuccess) break;
+    if ((e = launch_xsect_gather(h->stream, tmp, vout, n, (XsectRec*) xsects_dev)) != hipSuccess) break;
+    if ((e = launch_xsect_order_runs(h->stream, (XsectRec*) xsects_dev, n, im, h->map[im].seg, mid)) != hipSuccess) break;
+    // 4. locate the mid-points in the other map (query map id = im, map_overlay_lbvh.h:232-236)
+    if ((rc = rj_pip_query_async(h, 1 - im, im, mid, 0, n, closest, face))) break;
+    if ((e = launch_xsect_set_mid(h->stream, (XsectRec*) xsects_dev, n, im, face)) != hipSuccess) break;
+    e = hipStreamSynchronize(h->stream);
+  } while (0);
+  (void) hipFree(tmp); (void) hipFree(kin); (void) hipFree(kout); (void) hipFree(vin); (void) hipFree(vout);
+  (void) hipFree(closest); (void) hipFree(face); (void) hipFree(mid); (void) hipFree(temp);
+  if (rc) return rc;
+  RJ_HIP(h, e);
+  return RJ_OK;
+}
+
 int rj_last_ms(rj_handle h, int which, float* ms) {
   RJ_CHECK_H(h);
   if (which < 0 || which >= kNumTimers || !ms) return fail(h, RJ_E_INVALID, "rj_last_ms: bad timer");

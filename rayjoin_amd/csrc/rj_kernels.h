@@ -47,6 +47,10 @@ hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, co
                               uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n);
 hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
                          uint64_t* kout, uint64_t n);
+hipError_t launch_xsect_keys(hipStream_t st, const XsectRec* rec, uint64_t n, int im, uint64_t* keys, uint32_t* vals);
+hipError_t launch_xsect_gather(hipStream_t st, const XsectRec* in, const uint32_t* order, uint64_t n, XsectRec* out);
+hipError_t launch_xsect_order_runs(hipStream_t st, XsectRec* rec, uint64_t n, int im, const Seg* seg_im, int64_t* midpts);
+hipError_t launch_xsect_set_mid(hipStream_t st, XsectRec* rec, uint64_t n, int im, const int32_t* face);
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
 hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                 const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t n0p, Seg* sseg,

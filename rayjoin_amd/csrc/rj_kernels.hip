@@ -517,6 +517,78 @@ __global__ __launch_bounds__(256) void k_lsi_points(const Seg* __restrict__ seg0
   }
 }
 
+
+// =============================================================================================
+// Overlay support (src/app/map_overlay_lbvh.h:109-265, ComputeOutputPolygons): order the
+// intersections of every edge of map `im` along the edge, take the mid-points of consecutive
+// intersections (they are located in the other map by an ordinary PIP query) and store the face
+// found for each mid-point in the record that precedes it.
+// =============================================================================================
+__global__ __launch_bounds__(256) void k_xsect_keys(const XsectRec* __restrict__ rec, uint64_t n, int im,
+                                                    uint64_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+    const uint32_t mine = im ? rec[i].eid1 : rec[i].eid0, other = im ? rec[i].eid0 : rec[i].eid1;
+    keys[i] = ((uint64_t) mine << 32) | other;
+    vals[i] = (uint32_t) i;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_xsect_gather(const XsectRec* __restrict__ in, const uint32_t* __restrict__ order,
+                                                      uint64_t n, XsectRec* __restrict__ out) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+    out[i] = in[order[i]];
+}
+
+// squared distance of the stored (truncated) intersection point from p1, exact in int128
+// (map_overlay_lbvh.h:204-213: SQ(x - p1.x) + SQ(y - p1.y) on rational<__int128> with denominators 1)
+__device__ __forceinline__ u128 xsect_dist2(const XsectRec& r, int64_t px, int64_t py) {
+  const i128 dx = (i128) r.x_num - px, dy = (i128) r.y_num - py;
+  return (u128) (dx * dx) + (u128) (dy * dy);
+}
+
+// one thread per run of equal eid[im] (run starts are detected in place): stable insertion sort by
+// distance from the edge's p1 (runs are tiny; ties keep the other map's eid ascending), then the
+// mid-points.  Run ends get their own point as a dummy mid-point and keep mid = DONTKNOW.
+__global__ __launch_bounds__(256) void k_xsect_order_runs(XsectRec* __restrict__ rec, uint64_t n, int im,
+                                                          const Seg* __restrict__ seg_im,
+                                                          int64_t* __restrict__ midpts) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+    const uint32_t e = im ? rec[i].eid1 : rec[i].eid0;
+    if (i > 0 && (im ? rec[i - 1].eid1 : rec[i - 1].eid0) == e) continue;  // not a run start
+    uint64_t end = i + 1;
+    while (end < n && (im ? rec[end].eid1 : rec[end].eid0) == e) end++;
+    const Seg s = seg_im[e];
+    for (uint64_t a = i + 1; a < end; a++) {  // insertion sort of [i, end)
+      const XsectRec cur = rec[a];
+      const u128 dc = xsect_dist2(cur, s.x1, s.y1);
+      uint64_t b = a;
+      while (b > i && xsect_dist2(rec[b - 1], s.x1, s.y1) > dc) {
+        rec[b] = rec[b - 1];
+        b--;
+      }
+      rec[b] = cur;
+    }
+    for (uint64_t a = i; a < end; a++) {
+      int64_t mx = rec[a].x_num, my = rec[a].y_num;
+      if (a + 1 < end) {  // x1 + (x2 - x1) / 2 as a rational, then the narrowing store: trunc((x1 + x2) / 2)
+        mx = (int64_t) (((i128) rec[a].x_num + rec[a + 1].x_num) / 2);
+        my = (int64_t) (((i128) rec[a].y_num + rec[a + 1].y_num) / 2);
+      }
+      midpts[2 * a] = mx;
+      midpts[2 * a + 1] = my;
+      rec[a].mid = -1;  // DONTKNOW
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_xsect_set_mid(XsectRec* __restrict__ rec, uint64_t n, int im,
+                                                       const int32_t* __restrict__ face) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i + 1 < n; i += (uint64_t) gridDim.x * blockDim.x) {
+    const uint32_t a = im ? rec[i].eid1 : rec[i].eid0, b = im ? rec[i + 1].eid1 : rec[i + 1].eid0;
+    if (a == b) rec[i].mid = face[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, uint64_t n) {
   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n;
        i += (uint64_t) gridDim.x * blockDim.x) {
@@ -785,6 +857,23 @@ hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, co
 hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
                          uint64_t* kout, uint64_t n) {
   return rocprim::radix_sort_keys(temp, temp_bytes, kin, kout, (size_t) n, 0, 64, st);
+}
+
+hipError_t launch_xsect_keys(hipStream_t st, const XsectRec* rec, uint64_t n, int im, uint64_t* keys, uint32_t* vals) {
+  if (n) hipLaunchKernelGGL(k_xsect_keys, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, rec, n, im, keys, vals);
+  return hipGetLastError();
+}
+hipError_t launch_xsect_gather(hipStream_t st, const XsectRec* in, const uint32_t* order, uint64_t n, XsectRec* out) {
+  if (n) hipLaunchKernelGGL(k_xsect_gather, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, in, order, n, out);
+  return hipGetLastError();
+}
+hipError_t launch_xsect_order_runs(hipStream_t st, XsectRec* rec, uint64_t n, int im, const Seg* seg_im, int64_t* midpts) {
+  if (n) hipLaunchKernelGGL(k_xsect_order_runs, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, rec, n, im, seg_im, midpts);
+  return hipGetLastError();
+}
+hipError_t launch_xsect_set_mid(hipStream_t st, XsectRec* rec, uint64_t n, int im, const int32_t* face) {
+  if (n) hipLaunchKernelGGL(k_xsect_set_mid, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, rec, n, im, face);
+  return hipGetLastError();
 }
 
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {

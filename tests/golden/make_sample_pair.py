@@ -37,5 +37,10 @@ faces = m0.face_ids(eids)
 with open(os.path.join(D, "pip_answer.txt"), "w") as f:  # closest_eid face_id per vertex of map 1
     for e, fc in zip(eids, faces):
         f.write("%d %d\n" % (e, fc))
+# overlay answer (polyover_exec -output), produced by the oracle pipeline + tests/overlay_ref.py
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import overlay_ref  # noqa: E402
+(nch, nfc), _, _ = overlay_ref.oracle_overlay(O, ctx, os.path.join(D, "overlay_answer.txt"))
+print("overlay: %d chains, %d faces" % (nch, nfc))
 print("map0: %d edges, map1: %d edges, %d intersections, %d points (%d misses)"
       % (m0.ne, m1.ne, len(xs), len(eids), int((eids == O.MISS).sum())))
