@@ -66,22 +66,32 @@ __device__ __forceinline__ int rank_below(uint64_t m) {
 }
 __device__ __forceinline__ int32_t quant(int64_t v) { return (int32_t) ((v + kCoordOffset) >> kQuantShift); }
 
+// Wave64 reductions on the VALU's DPP path (no LDS crossbar round trips): quad swaps, row rotates,
+// then row_bcast:15 / row_bcast:31 fold the four 16-lane rows; the total lands in lane 63 and is
+// returned wave-uniform.  min/max are idempotent, so lanes outside a row_mask keeping their own
+// value is harmless.
+#define RJ_DPP_STEP(OP, v, ctrl, rmask) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false))
+__device__ __forceinline__ int32_t rj_min32(int32_t a, int32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ int32_t rj_max32(int32_t a, int32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    int32_t t = __shfl_xor(v, o, 64);
-    v = t < v ? t : v;
-  }
-  return v;
+  RJ_DPP_STEP(rj_min32, v, 0xb1, 0xf);   // quad_perm:[1,0,3,2]
+  RJ_DPP_STEP(rj_min32, v, 0x4e, 0xf);   // quad_perm:[2,3,0,1]
+  RJ_DPP_STEP(rj_min32, v, 0x124, 0xf);  // row_ror:4
+  RJ_DPP_STEP(rj_min32, v, 0x128, 0xf);  // row_ror:8
+  RJ_DPP_STEP(rj_min32, v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
+  RJ_DPP_STEP(rj_min32, v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int32_t wave_max(int32_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    int32_t t = __shfl_xor(v, o, 64);
-    v = t > v ? t : v;
-  }
-  return v;
+  RJ_DPP_STEP(rj_max32, v, 0xb1, 0xf);
+  RJ_DPP_STEP(rj_max32, v, 0x4e, 0xf);
+  RJ_DPP_STEP(rj_max32, v, 0x124, 0xf);
+  RJ_DPP_STEP(rj_max32, v, 0x128, 0xf);
+  RJ_DPP_STEP(rj_max32, v, 0x142, 0xa);
+  RJ_DPP_STEP(rj_max32, v, 0x143, 0xc);
+  return __builtin_amdgcn_readlane(v, 63);
 }
+#undef RJ_DPP_STEP
 __device__ __forceinline__ int32_t bcast(int32_t v, int src_lane_uniform) {
   return __builtin_amdgcn_readlane(v, src_lane_uniform);
 }
