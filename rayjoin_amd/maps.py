@@ -267,7 +267,8 @@ class Context:
             if g is not None:
                 bb = [min(bb[0], g.bb[0]), min(bb[1], g.bb[1]), max(bb[2], g.bb[2]), max(bb[3], g.bb[3])]
         self.bb = tuple(bb)
-        self.scaling = Scaling(self.bb)
+        # no planar graph (maps injected later through set_map / .maps): leave the scaling unset
+        self.scaling = Scaling(self.bb) if any(g is not None for g in self.planar_graphs) else None
         self.maps = [None, None]
 
     def load(self):

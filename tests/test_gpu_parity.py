@@ -173,6 +173,32 @@ def test_query_ordering_modes_agree(oracle, lattice_pair):
     assert h.last_ms(_capi.RJ_T_ORDER) > 0  # the always-mode ran the ordering pass
 
 
+def test_two_handles_from_two_threads(oracle, lattice_pair):
+    """A handle is not thread-safe, but different handles may be used from different threads
+    (include/rayjoin_amd.h conventions); ctypes drops the GIL during the calls."""
+    import threading
+    ctx, _ = lattice_pair
+    want = oracle.lsi_brute(_omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1]))
+    out = {}
+
+    def work(tag, base):
+        d = ops.DeviceContext(ctx).LoadToDevice()
+        d.BuildIndex(base)
+        for _ in range(5):
+            lsi = _lsi(d, 1 - base, 100000)
+            out[tag] = lsi.get_pairs()
+        d.close()
+
+    ts = [threading.Thread(target=work, args=(i, i % 2)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(out) == 4
+    for v in out.values():
+        assert np.array_equal(v, want)
+
+
 def test_adversarial_chains_face_ids(oracle):
     pa = synth.adversarial_chains(60, 9, 12, 21)
     pb = synth.adversarial_chains(80, 5, 12, 22)
