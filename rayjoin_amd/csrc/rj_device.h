@@ -101,8 +101,23 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// Closed-interval box overlap as ONE sign test: every difference below is non-negative exactly
+// when the corresponding inequality holds, and no difference can overflow (coordinates are 31-bit
+// quantised values, empty boxes are {INT_MAX, INT_MAX, -1, -1}).  Three ORs and one compare on
+// the VALU replace four compares and three scalar ANDs -- the scalar unit (one per CU, shared by
+// four SIMDs) is the scarcer issue port in the traversal loops.
+__device__ __forceinline__ bool boxes_overlap(int32_t ax0, int32_t ay0, int32_t ax1, int32_t ay1, int32_t bx0,
+                                              int32_t by0, int32_t bx1, int32_t by1) {
+  return ((bx1 - ax0) | (ax1 - bx0) | (by1 - ay0) | (ay1 - by0)) >= 0;
+}
 __device__ __forceinline__ bool overlap(const QBox& a, int32_t bx0, int32_t by0, int32_t bx1, int32_t by1) {
-  return a.x0 <= bx1 && bx0 <= a.x1 && a.y0 <= by1 && by0 <= a.y1;
+  return boxes_overlap(a.x0, a.y0, a.x1, a.y1, bx0, by0, bx1, by1);
+}
+// PIP relevance of a box for a point: x0 <= qx <= x1, y1 >= qy - 1, y0 <= qbest
+// (qym1 = max(qy - 1, 0) keeps every difference inside 32 bits; qbest = -1 marks an idle lane)
+__device__ __forceinline__ bool ray_can_hit(int32_t qx, int32_t qym1, int32_t qbest, int32_t x0, int32_t y0,
+                                            int32_t x1, int32_t y1) {
+  return ((qx - x0) | (x1 - qx) | (y1 - qym1) | (qbest - y0)) >= 0;
 }
 
 }  // namespace rj

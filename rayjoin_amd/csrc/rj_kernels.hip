@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
         um &= um - 1;
         const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        if (__ballot(qx0 <= cx1 && cx0 <= qx1 && qy0 <= cy1 && cy0 <= qy1)) keep |= 1ull << c;
+        if (__ballot(boxes_overlap(qx0, qy0, qx1, qy1, cx0, cy0, cx1, cy1))) keep |= 1ull << c;
       }
       return keep;
     };
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       py = __builtin_nontemporal_load(A.pts + 2 * ip + 1);
     }
     const int32_t qx = quant(px), qy = quant(py);
+    const int32_t qym1 = qy > 0 ? qy - 1 : 0;
     const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
     const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
     const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
@@ -712,7 +713,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         um &= um - 1;
         const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        const uint64_t bal = __ballot(cx0 <= qx && qx <= cx1 && cy1 >= qy - 1 && cy0 <= qbest);
+        const uint64_t bal = __ballot(ray_can_hit(qx, qym1, qbest, cx0, cy0, cx1, cy1));
         if (bal) {
           keep |= 1ull << c;
           if (lane == c) {
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
           if (!__ballot(act)) break;
           const int32_t sx0 = __shfl(bb.x0, jj, 64), sx1 = __shfl(bb.x1, jj, 64);
           const int32_t sy0 = __shfl(bb.y0, jj, 64), sy1 = __shfl(bb.y1, jj, 64);
-          if (act && sx1 >= qx && sy1 >= qy - 1 && sy0 <= qbest) {
+          if (act && ray_can_hit(qx, qym1, qbest, sx0, sy0, sx1, sy1)) {
             L.cand[cnt][lane] = slot0 + (uint32_t) jj;
             // certain hit (strictly inside in x, strictly above) => its box top bounds the answer
             const bool certain = sx0 < qx && qx < sx1 && sy0 > qy;
