@@ -610,11 +610,10 @@ __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, u
 constexpr int kPipList = 8;     // candidate slots per lane between two exact-evaluation rounds
 constexpr int kPipStack = 64 * 4;  // >= 63 * (levels - 1) + 64 entries for <= 4 expanded levels
 
-// A stack entry carries the node's y0 and the mask of lanes that could use it when it was pushed,
-// so a stale entry (every interested lane has since found something lower) is dropped at pop time
-// without touching memory.
+// A stack entry carries the node's y0 and x-range, so a stale entry (every lane under it has since
+// found something lower) is dropped at pop time without touching memory.
 struct PipWaveLds {
-  uint4 stack[kPipStack];  // {level<<28 | index, y0, lane mask lo, lane mask hi}
+  uint4 stack[kPipStack];  // {level<<28 | index, y0, x0, x1}
   uint32_t cand[kPipList][64];
 };
 
@@ -703,9 +702,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       if (STATS) tk_drain += clock64() - tk0;
     };
 
-    // a child survives only if SOME lane's upward ray can still hit it; the lanes that can are
-    // remembered per child (mlo/mhi of the lane holding that child) for the pop-time re-check
-    uint32_t mlo = 0, mhi = 0;
+    // a child survives only if SOME lane's upward ray can still hit it
     auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
       uint64_t keep = 0;
       while (um) {
@@ -713,14 +710,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         um &= um - 1;
         const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        const uint64_t bal = __ballot(ray_can_hit(qx, qym1, qbest, cx0, cy0, cx1, cy1));
-        if (bal) {
-          keep |= 1ull << c;
-          if (lane == c) {
-            mlo = (uint32_t) bal;
-            mhi = (uint32_t) (bal >> 32);
-          }
-        }
+        if (__ballot(ray_can_hit(qx, qym1, qbest, cx0, cy0, cx1, cy1))) keep |= 1ull << c;
       }
       return keep;
     };
@@ -732,7 +722,8 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       const int n = __popcll(m);
       // reversed so that lane 0's child (lowest Morton = lowest y half) pops first
       if ((m >> lane) & 1)
-        L.stack[n - 1 - rank_below(m)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, mlo, mhi);
+        L.stack[n - 1 - rank_below(m)] =
+            make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
       sp = n;
       wave_lds_fence();
     }
@@ -742,9 +733,10 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       --sp;
       const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
       const int32_t ey0 = (int32_t) __builtin_amdgcn_readfirstlane(ent.y);
-      const uint64_t emask = ((uint64_t) __builtin_amdgcn_readfirstlane(ent.w) << 32) | __builtin_amdgcn_readfirstlane(ent.z);
-      // stale?  (every lane that wanted this node has a bound below it by now)
-      if (!__ballot(((emask >> lane) & 1) && ey0 <= qbest)) {
+      const int32_t ex0 = (int32_t) __builtin_amdgcn_readfirstlane(ent.z), ex1 = (int32_t) __builtin_amdgcn_readfirstlane(ent.w);
+      // stale?  (every lane under this node's x-range has a bound below it by now)
+      const bool want = ((qx - ex0) | (ex1 - qx) | (qbest - ey0)) >= 0;
+      if (!__ballot(want)) {
         if (STATS) st_stale++;
         continue;
       }
@@ -757,7 +749,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         const int n = __popcll(m);
         if ((m >> lane) & 1)
           L.stack[sp + n - 1 - rank_below(m)] =
-              make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, mlo, mhi);
+              make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
         sp += n;
         if (STATS) st_nodes++;
         wave_lds_fence();
@@ -769,8 +761,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         const QBox bb = T.box0[(uint64_t) slot0 + lane];  // one base segment per lane, sorted by x0
         const int32_t pm = T.pmx1[(uint64_t) slot0 + lane];
         if (STATS) st_leaf++;
-        // lanes whose ray cannot use this block any more (or never could) sit the visit out
-        const bool want = ((emask >> lane) & 1) && ey0 <= qbest;
+        // (lanes whose ray cannot use this block any more, or never could, sit the visit out: `want`)
         const int ub = wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
         int j = want ? ub - 1 : -1;
         for (;;) {
