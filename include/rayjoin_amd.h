@@ -122,6 +122,27 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
                        uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev,
                        int32_t* face_id_dev);
 
+/* ---- multi-GPU: RCCL over xGMI ---------------------------------------------------------- */
+/* New design (the reference is single-GPU: no NCCL/MPI anywhere).  One process and
+ * one handle per GPU; the query map is sharded by chain range (rj_lsi_query's eid range / the point
+ * range of rj_pip_query), the base map + LBVH are replicated, and the result queues are exchanged
+ * with an all-gather-v: counts first (ncclAllGather), then every rank's exact slice straight into
+ * its offset of the output (grouped ncclSend/ncclRecv -- no padding).
+ * rj_comm_unique_id: call on ONE rank, hand the 128 bytes to the others out of band (file, env,
+ * MPI, torch.distributed store ...).  rj_comm_init is collective. */
+#define RJ_COMM_ID_BYTES 128
+int rj_comm_unique_id(uint8_t id[RJ_COMM_ID_BYTES]);
+int rj_comm_init(rj_handle h, int nranks, int rank, const uint8_t id[RJ_COMM_ID_BYTES]);
+int rj_comm_destroy(rj_handle h);
+/* pairs_dev: this rank's n_local (eid0, eid1) pairs; out_dev[2 * out_capacity]: all ranks' pairs in
+ * rank order; counts_out[nranks] (host, nullable); *n_total = sum.  RJ_E_OVERFLOW (with *n_total
+ * set) when the total exceeds out_capacity. */
+int rj_allgather_pairs(rj_handle h, const uint32_t* pairs_dev, uint64_t n_local, uint32_t* out_dev,
+                       uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total);
+/* same for a queue of 32-bit values (closest eids / face ids of a point shard) */
+int rj_allgather_u32(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uint32_t* out_dev,
+                     uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total);
+
 /* ---- overlay support ------------------------------------------------------------------- */
 /* replaces: the per-map body of MapOverlayLBVH::ComputeOutputPolygons
  * (src/app/map_overlay_lbvh.h:109-265).  For map `im`: the n intersections (eid map 0, eid map 1)

@@ -38,6 +38,11 @@ SYMBOLS = {
     "rj_lsi_query_finish": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "rj_lsi_points": (_int, [_vp, _vp, _u64, _vp]),
     "rj_sort_pairs": (_int, [_vp, _vp, _u64]),
+    "rj_comm_unique_id": (_int, [_vp]),
+    "rj_comm_init": (_int, [_vp, _int, _int, _vp]),
+    "rj_comm_destroy": (_int, [_vp]),
+    "rj_allgather_pairs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
+    "rj_allgather_u32": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
     "rj_overlay_edge_xsects": (_int, [_vp, _int, _vp, _u64, _vp]),
     "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
@@ -221,6 +226,37 @@ class Handle:
 
     def lsi_points(self, pairs_dev, n, out_dev):
         self._check(self.L.rj_lsi_points(self.h, _ptr(pairs_dev), n, _ptr(out_dev)))
+
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = load().rj_comm_unique_id(buf)
+        if rc != RJ_OK:
+            raise RayJoinError(rc, "rj_comm_unique_id failed")
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self.L.rj_comm_init(self.h, nranks, rank, buf))
+        self.nranks = nranks
+
+    def comm_destroy(self):
+        self._check(self.L.rj_comm_destroy(self.h))
+
+    def _allgather(self, fn, src_dev, n_local, out_dev, out_capacity):
+        counts = (_u64 * getattr(self, "nranks", 1))()
+        tot = _u64()
+        rc = fn(self.h, _ptr(src_dev), n_local, _ptr(out_dev), out_capacity, counts, C.byref(tot))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), tot.value)
+        self._check(rc)
+        return tot.value, list(counts)
+
+    def allgather_pairs(self, pairs_dev, n_local, out_dev, out_capacity):
+        return self._allgather(self.L.rj_allgather_pairs, pairs_dev, n_local, out_dev, out_capacity)
+
+    def allgather_u32(self, src_dev, n_local, out_dev, out_capacity):
+        return self._allgather(self.L.rj_allgather_u32, src_dev, n_local, out_dev, out_capacity)
 
     def overlay_edge_xsects(self, im, pairs_dev, n, xsects_dev):
         self._check(self.L.rj_overlay_edge_xsects(self.h, im, _ptr(pairs_dev), n, _ptr(xsects_dev)))

@@ -1,6 +1,7 @@
 // rj_api.hip -- the C ABI of include/rayjoin_amd.h on top of the kernels in rj_kernels.hip.
 // Host-side orchestration only (allocation, upload, launch order, timing events).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -73,6 +74,9 @@ struct rj_handle_s {
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 4;      // consecutive 64-query groups handed to a wave at a time
   uint64_t last_stats[16] = {0};
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  unsigned long long* d_counts = nullptr;  // [nranks] gathered counts
   std::string err;
 };
 
@@ -177,6 +181,8 @@ int rj_destroy(rj_handle h) {
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
+  if (h->comm) (void) ncclCommDestroy(h->comm);
+  (void) hipFree(h->d_counts);
   (void) hipStreamDestroy(h->own_stream);
   delete h;
   return RJ_OK;
@@ -548,6 +554,101 @@ int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* 
   return RJ_OK;
 }
 
+
+#define RJ_NCCL(h, expr)                                                                          \
+  do {                                                                                            \
+    ncclResult_t _r = (expr);                                                                     \
+    if (_r != ncclSuccess)                                                                        \
+      return fail(h, RJ_E_HIP, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(_r), __FILE__, __LINE__); \
+  } while (0)
+
+int rj_comm_unique_id(uint8_t id[RJ_COMM_ID_BYTES]) {
+  static_assert(RJ_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  if (!id) return RJ_E_INVALID;
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return RJ_E_HIP;
+  memcpy(id, u.internal, RJ_COMM_ID_BYTES);
+  return RJ_OK;
+}
+
+int rj_comm_init(rj_handle h, int nranks, int rank, const uint8_t id[RJ_COMM_ID_BYTES]) {
+  RJ_CHECK_H(h);
+  if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, RJ_E_INVALID, "rj_comm_init: bad arguments");
+  if (h->comm) return fail(h, RJ_E_INVALID, "rj_comm_init: communicator already initialised");
+  if (int r = set_device(h)) return r;
+  ncclUniqueId u;
+  memcpy(u.internal, id, RJ_COMM_ID_BYTES);
+  RJ_NCCL(h, ncclCommInitRank(&h->comm, nranks, u, rank));
+  h->nranks = nranks;
+  h->rank = rank;
+  if (int r = dev_alloc(h, &h->d_counts, (uint64_t) nranks)) return r;
+  return RJ_OK;
+}
+
+int rj_comm_destroy(rj_handle h) {
+  RJ_CHECK_H(h);
+  if (h->comm) {
+    if (int r = set_device(h)) return r;
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    RJ_NCCL(h, ncclCommDestroy(h->comm));
+    h->comm = nullptr;
+    (void) hipFree(h->d_counts);
+    h->d_counts = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+  }
+  return RJ_OK;
+}
+
+// all-gather-v of n_local elements of `elt_words` 32-bit words each
+static int allgatherv_words(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uint32_t* out_dev,
+                            uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total, int elt_words) {
+  if (!h->comm) return fail(h, RJ_E_INVALID, "call rj_comm_init first");
+  if ((n_local && !src_dev) || (out_capacity && !out_dev)) return fail(h, RJ_E_INVALID, "null buffer");
+  if (int r = set_device(h)) return r;
+  const int P = h->nranks;
+  // 1. counts
+  unsigned long long mine = n_local;
+  RJ_HIP(h, hipMemcpyAsync(h->d_counts + h->rank, &mine, 8, hipMemcpyHostToDevice, h->stream));
+  RJ_NCCL(h, ncclAllGather(h->d_counts + h->rank, h->d_counts, 1, ncclUint64, h->comm, h->stream));
+  std::vector<unsigned long long> cnt(P);
+  RJ_HIP(h, hipMemcpyAsync(cnt.data(), h->d_counts, 8 * (size_t) P, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  uint64_t total = 0;
+  std::vector<uint64_t> off(P);
+  for (int r = 0; r < P; r++) { off[r] = total; total += cnt[r]; if (counts_out) counts_out[r] = cnt[r]; }
+  if (n_total) *n_total = total;
+  if (total > out_capacity)
+    return fail(h, RJ_E_OVERFLOW, "all-gather-v: %llu elements in total, capacity %llu", (unsigned long long) total,
+                (unsigned long long) out_capacity);
+  // 2. exact slices: my slice goes to every peer, every peer's slice lands at its offset here
+  const size_t w = (size_t) elt_words;
+  if (n_local)
+    RJ_HIP(h, hipMemcpyAsync(out_dev + off[h->rank] * w, src_dev, n_local * w * 4, hipMemcpyDeviceToDevice, h->stream));
+  if (P > 1) {
+    RJ_NCCL(h, ncclGroupStart());
+    for (int r = 0; r < P; r++) {
+      if (r == h->rank) continue;
+      if (n_local) RJ_NCCL(h, ncclSend(src_dev, n_local * w, ncclUint32, r, h->comm, h->stream));
+      if (cnt[r]) RJ_NCCL(h, ncclRecv(out_dev + off[r] * w, cnt[r] * w, ncclUint32, r, h->comm, h->stream));
+    }
+    RJ_NCCL(h, ncclGroupEnd());
+  }
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  return RJ_OK;
+}
+
+int rj_allgather_pairs(rj_handle h, const uint32_t* pairs_dev, uint64_t n_local, uint32_t* out_dev,
+                       uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total) {
+  RJ_CHECK_H(h);
+  return allgatherv_words(h, pairs_dev, n_local, out_dev, out_capacity, counts_out, n_total, 2);
+}
+
+int rj_allgather_u32(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uint32_t* out_dev,
+                     uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total) {
+  RJ_CHECK_H(h);
+  return allgatherv_words(h, src_dev, n_local, out_dev, out_capacity, counts_out, n_total, 1);
+}
 
 int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint64_t n, rj_xsect* xsects_dev) {
   RJ_CHECK_H(h);

@@ -62,6 +62,25 @@ struct HostMap {
   size_t n_points() const { return xy.size() / 2; }
   size_t n_chains() const { return left.size(); }
   size_t n_edges() const { return n_points() - n_chains(); }
+  // contiguous chain range of shard `rank` of `nranks`, balanced by edge count; a chain range is a
+  // contiguous eid range [e0, e1) and point range [p0, p1) because eid = p_idx - ichain (map.h:200-203)
+  void shard(int nranks, int rank, size_t* e0, size_t* e1, size_t* p0, size_t* p1) const {
+    const size_t nc = n_chains(), ne = n_edges();
+    auto cut = [&](int r) -> size_t {  // first chain c with (#edges before c) >= r * ne / nranks
+      if (r <= 0) return 0;
+      if (r >= nranks) return nc;
+      const double target = (double) r * (double) ne / nranks;
+      size_t lo = 0, hi = nc;
+      while (lo < hi) {
+        size_t mid = (lo + hi) / 2;
+        if ((double) (row_index[mid] - mid) >= target) hi = mid; else lo = mid + 1;
+      }
+      return lo;
+    };
+    const size_t c0 = cut(rank), c1 = std::max(cut(rank + 1), c0);
+    *e0 = row_index[c0] - c0; *e1 = row_index[c1] - c1;
+    *p0 = row_index[c0]; *p1 = row_index[c1];
+  }
 };
 
 class Context {

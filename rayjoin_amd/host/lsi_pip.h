@@ -23,6 +23,25 @@ class LSI {
   }
   virtual void Query(int query_map_id) = 0;
   size_t size() const { return n_; }
+  size_t local_size() const { return n_local_; }
+  // restrict Query to the eid range of this rank's shard of the query map (default: every edge)
+  void set_query_range(size_t e0, size_t e1) { e0_ = e0; e1_ = e1; ranged_ = true; }
+  // all-gather-v of every rank's intersection queue (rj_comm_init first); afterwards this object
+  // holds ALL pairs, in rank order
+  uint64_t AllGather(size_t capacity) {
+    rj_handle h = ctx_.handle();
+    uint32_t* all = nullptr;
+    rj_check(h, rj_dev_alloc(h, 8 * (capacity ? capacity : 1), (void**) &all), "rj_dev_alloc");
+    uint64_t total = 0;
+    int rc = rj_allgather_pairs(h, queue_, n_, all, capacity, nullptr, &total);
+    if (rc != RJ_OK) { rj_dev_free(h, all); rj_check(h, rc, "rj_allgather_pairs"); }
+    n_local_ = n_;
+    rj_dev_free(h, queue_);
+    queue_ = all;
+    n_ = total;
+    cap_ = capacity;
+    return total;
+  }
   // 48-byte Intersection records on the host, sorted by (eid[0], eid[1])
   void CopyTo(std::vector<xsect_t>& out) {
     rj_handle h = ctx_.handle();
@@ -39,7 +58,9 @@ class LSI {
   Context& ctx_;
   uint32_t* queue_ = nullptr;  // (eid map 0, eid map 1) pairs, device
   rj_xsect* xsects_ = nullptr;
-  size_t cap_ = 0, n_ = 0;
+  size_t cap_ = 0, n_ = 0, n_local_ = 0;
+  size_t e0_ = 0, e1_ = 0;
+  bool ranged_ = false;
 };
 
 class LSILBVH : public LSI {
@@ -47,8 +68,8 @@ class LSILBVH : public LSI {
   explicit LSILBVH(Context& ctx) : LSI(ctx) {}
   void Query(int query_map_id) override {
     uint64_t n = 0;
-    int rc = rj_lsi_query(ctx_.handle(), 1 - query_map_id, query_map_id, 0, ctx_.get_map(query_map_id)->n_edges(),
-                          cap_, queue_, &n);
+    const size_t qb = ranged_ ? e0_ : 0, qe = ranged_ ? e1_ : ctx_.get_map(query_map_id)->n_edges();
+    int rc = rj_lsi_query(ctx_.handle(), 1 - query_map_id, query_map_id, qb, qe, cap_, queue_, &n);
     n_ = n < cap_ ? n : cap_;
     rj_check(ctx_.handle(), rc, "rj_lsi_query");
   }

@@ -4,7 +4,10 @@
 //   -mode=rt   : rejected -- gfx950 has no ray-tracing units (the reference's OptiX path)
 //   -mode=grid : rejected here -- the uniform-grid algorithm exists in this repository only as
 //                the CPU parity oracle (oracle/, test infrastructure), never as a product path
+#include <unistd.h>
+
 #include <cstdio>
+#include <fstream>
 #include <iostream>
 #include <random>
 
@@ -60,6 +63,27 @@ std::vector<int64_t> GeneratePIPQueries(const Flags& f, Context& ctx) {
   return pts;
 }
 
+// one process per GPU: rank 0 creates the RCCL id and publishes it through a file
+void InitComm(const Flags& f, Context& ctx) {
+  if (f.nranks <= 1 && f.comm_file.empty()) return;
+  if (f.comm_file.empty()) throw std::invalid_argument("-nranks > 1 needs -comm_file <path shared by all ranks>");
+  uint8_t id[RJ_COMM_ID_BYTES];
+  if (f.rank == 0) {
+    if (rj_comm_unique_id(id) != RJ_OK) throw std::runtime_error("rj_comm_unique_id failed");
+    std::string tmp = f.comm_file + ".tmp";
+    std::ofstream(tmp, std::ios::binary).write(reinterpret_cast<char*>(id), sizeof(id));
+    if (rename(tmp.c_str(), f.comm_file.c_str())) throw std::runtime_error("cannot publish " + f.comm_file);
+  } else {
+    for (int tries = 0;; tries++) {
+      std::ifstream in(f.comm_file, std::ios::binary);
+      if (in.read(reinterpret_cast<char*>(id), sizeof(id))) break;
+      if (tries > 600) throw std::runtime_error("timed out waiting for " + f.comm_file);
+      usleep(100000);
+    }
+  }
+  rj_check(ctx.handle(), rj_comm_init(ctx.handle(), f.nranks, f.rank, id), "rj_comm_init");
+}
+
 void CheckMode(const Flags& f) {
   if (f.mode == "lbvh") return;
   if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
@@ -92,6 +116,13 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
   size_t queue_cap = (size_t) ((ctx->get_map(0)->n_edges() + ctx->get_map(1)->n_edges()) * f.xsect_factor);
   std::cerr << "Queue capacity: " << queue_cap << std::endl;
   lsi.Init(queue_cap);
+  InitComm(f, *ctx);
+  size_t e0 = 0, e1 = ctx->get_map(1)->n_edges(), p0 = 0, p1 = 0;
+  if (f.nranks > 1) {
+    ctx->get_map(1)->shard(f.nranks, f.rank, &e0, &e1, &p0, &p1);
+    std::cerr << "Rank " << f.rank << "/" << f.nranks << ": query eids [" << e0 << ", " << e1 << ")" << std::endl;
+  }
+  lsi.set_query_range(e0, e1);
   tm.next("Build Index");
   rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
   tm.next("Warmup");
@@ -106,6 +137,10 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
     kernel_ms += ms;
   }
   tm.next("Cleanup");
+  if (!f.comm_file.empty()) {  // all-gather-v of the intersection queues over RCCL
+    uint64_t total = lsi.AllGather(queue_cap);
+    std::cerr << "Rank " << f.rank << ": local intersections " << lsi.local_size() << ", all ranks " << total << std::endl;
+  }
   std::cerr << "Intersections: " << lsi.size() << " Queue Load Factor: " << (double) lsi.size() / (queue_cap ? queue_cap : 1)
             << std::endl;
   if (f.repeat > 0) std::cerr << "LSI kernel (HIP events): " << kernel_ms / f.repeat << " ms" << std::endl;

@@ -49,3 +49,37 @@ def test_query_exec_lsi_and_pip(oracle, tmp_path):
     r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "lbvh", "-xsect_factor", "0.000001",
                         "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)
     assert r.returncode == 3 and "overflow" in r.stderr
+
+
+def test_native_rccl_allgatherv_single_rank(oracle, tmp_path):
+    """The C-ABI's RCCL path with a 1-rank communicator (all a 1-GPU box allows): counts
+    all-gather + exact-slice exchange reduce to the identity; query_exec drives it end to end."""
+    from rayjoin_amd import _capi, ops
+    ctx = maps.Context([synth.lattice_map(7, 100, 51), synth.lattice_map(15, 44, 52)]).load()
+    d = ops.DeviceContext(ctx).LoadToDevice()
+    d.BuildIndex(0)
+    h = d.handle
+    h.comm_init(1, 0, _capi.Handle.comm_unique_id())
+    lsi = ops.LSILBVH(d)
+    lsi.Init(100000)
+    n = lsi.Query(1)
+    out = h.alloc(8 * 100000)
+    total, counts = h.allgather_pairs(lsi.queue, n, out, 100000)
+    assert total == n and counts == [n]
+    assert np.array_equal(out.to_host(np.uint32, 2 * n), lsi.queue.to_host(np.uint32, 2 * n))
+    ids = h.alloc(4 * 1000)
+    src = h.alloc(4 * 1000).from_host(np.arange(1000, dtype=np.uint32))
+    total, counts = h.allgather_u32(src, 1000, ids, 1000)
+    assert total == 1000 and np.array_equal(ids.to_host(np.uint32), np.arange(1000, dtype=np.uint32))
+    with pytest.raises(_capi.QueueOverflow):
+        h.allgather_u32(src, 1000, ids, 10)
+    h.comm_destroy()
+    d.close()
+    p0, p1 = str(tmp_path / "a.cdb"), str(tmp_path / "b.cdb")
+    maps.write_cdb(p0, synth.lattice_map(7, 100, 51), "%.9f")
+    maps.write_cdb(p1, synth.lattice_map(15, 44, 52), "%.9f")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "lbvh", "-xsect_factor", "0.5",
+                        "-warmup", "0", "-repeat", "1", "-nranks", "1", "-rank", "0", "-comm_file", str(tmp_path / "id")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert re.search(r"all ranks (\d+)", r.stderr)
