@@ -352,7 +352,7 @@ __device__ __forceinline__ void lsi_drain(LsiWaveLds& L, int& np, int& nh, int n
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
+__global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
   __shared__ LsiWaveLds lds[4];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
@@ -428,14 +428,14 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
       wave_lds_fence();
     }
     if (STATS) tk_head += clock64() - tkg;
-    while (sp > 0) {
-      uint32_t e = __builtin_amdgcn_readfirstlane(L.stack[sp - 1]);
-      --sp;
+    // Order is irrelevant for LSI (nothing prunes), so the stack is consumed two entries at a time
+    // with both entries' boxes requested before either is processed: two dependent-load chains in
+    // flight per wave instead of one (the kernel is bound by the latency of these loads).
+    auto process = [&](uint32_t e, const QBox& b, int32_t pm) {
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
       const long long tk0 = STATS ? clock64() : 0;
       if (lvl > 1) {
-        QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
         uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
         sp += __popcll(m);
@@ -447,16 +447,14 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
         // the prefix with x0 <= its x1 and scans it backwards while pmx1 says an x-overlap is
         // still possible.
         const uint32_t slot0 = idx * 64;
-        const QBox bb = T.box0[(uint64_t) slot0 + lane];
-        const int32_t pm = T.pmx1[(uint64_t) slot0 + lane];
         if (STATS) st_leaf++;
-        int j = wave_upper_bound(bb.x0, qx1) - 1;  // invalid lanes: qx1 = -1 -> j = -1
+        int j = wave_upper_bound(b.x0, qx1) - 1;  // invalid lanes: qx1 = -1 -> j = -1
         for (;;) {
           const int jj = j < 0 ? 0 : j;
           const int32_t pmj = __shfl(pm, jj, 64);
           const bool act = j >= 0 && pmj >= qx0;
           if (!__ballot(act)) break;
-          const int32_t sx1 = __shfl(bb.x1, jj, 64), sy0 = __shfl(bb.y0, jj, 64), sy1 = __shfl(bb.y1, jj, 64);
+          const int32_t sx1 = __shfl(b.x1, jj, 64), sy0 = __shfl(b.y0, jj, 64), sy1 = __shfl(b.y1, jj, 64);
           const bool c = act && sx1 >= qx0 && qy0 <= sy1 && sy0 <= qy1;  // (x0[j] <= qx1 by construction)
           const uint64_t cm = __ballot(c);
           if (STATS) st_box++;
@@ -470,6 +468,26 @@ __global__ __launch_bounds__(256, 5) void k_lsi(LsiArgs A) {
         }
         if (STATS) tk_leaf += clock64() - tk0;
       }
+    };
+    auto fetch = [&](uint32_t e, QBox& b, int32_t& pm) {
+      const int lvl = (int) (e >> 28);
+      const uint64_t c = (uint64_t) (e & 0x0FFFFFFFu) * 64 + lane;
+      // one address for both kinds of entry keeps the loads branch-free (pmx1 is only meaningful for leaves)
+      const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
+      b = src[c];
+      pm = T.pmx1[lvl > 1 ? (uint64_t) lane : c];
+    };
+    while (sp > 0) {
+      const bool two = sp > 1;
+      const uint32_t ea = __builtin_amdgcn_readfirstlane(L.stack[sp - 1]);
+      const uint32_t eb = __builtin_amdgcn_readfirstlane(L.stack[two ? sp - 2 : sp - 1]);
+      sp -= two ? 2 : 1;
+      QBox ba, bb2;
+      int32_t pma, pmb;
+      fetch(ea, ba, pma);
+      fetch(eb, bb2, pmb);
+      process(ea, ba, pma);
+      if (two) process(eb, bb2, pmb);
     }
   }
   }
