@@ -801,7 +801,28 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
           if (__ballot(cnt >= kPipList)) evaluate(false);
           j--;
         }
+        const int32_t gbest_before = gbest;
         gbest = wave_max(qbest);
+        if (gbest < gbest_before && sp > 1) {
+          // The bound of the whole group dropped: sweep the stack once, 64 entries per pass, and
+          // drop every entry that starts above it (order preserved).  One pass replaces a dozen
+          // one-at-a-time stale pops.
+          int kept = 0;
+          for (int base = 0; base < sp; base += 64) {
+            const int i = base + lane;
+            const bool have = i < sp;
+            uint4 en = make_uint4(0, 0, 0, 0);
+            if (have) en = L.stack[i];
+            const bool alive = have && (int32_t) en.y <= gbest;
+            const uint64_t am = __ballot(alive);
+            wave_lds_fence();
+            if (alive) L.stack[kept + rank_below(am)] = en;
+            kept += __popcll(am);
+          }
+          if (STATS) st_stale += (unsigned long long) (sp - kept);
+          sp = kept;
+          wave_lds_fence();
+        }
         if (STATS) tk_leaf += (clock64() - tk0) - (tk_drain - tkd0);
       }
     }
