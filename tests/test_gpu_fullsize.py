@@ -69,3 +69,33 @@ def test_uscounty_blockgroup_full_size(oracle):
     assert np.array_equal(c.to_host(np.uint32), eids[:m][perm])
     assert h.last_ms(_capi.RJ_T_ORDER) > 0
     h.close()
+
+
+def test_four_level_tree_parity(oracle):
+    """A base map big enough for a 4-level tree (24.4 M segments -> 382 k leaf blocks > 64^3):
+    WaterBodies stand-in as base, a 2 M-segment / 2 M-point slice of BlockGroup as queries,
+    bit-exact against the oracle's grid."""
+    oracle.lib().rjo_set_num_threads(16)
+    ctx = maps.Context([synth.standin("WaterBodies"), synth.standin("BlockGroup", 0.27)]).load()
+    base, query = ctx.maps
+    assert base.n_edges > 64 ** 3 * 64
+    h = _capi.Handle(0)
+    h.upload_map(0, base.pts, base.row_index, base.left, base.right)
+    h.upload_map(1, query.pts, query.row_index, query.left, query.right)
+    h.build_lbvh(0)
+    cap = int(0.2 * (base.n_edges + query.n_edges))
+    pairs = h.alloc(8 * cap)
+    n = h.lsi_query(0, 1, 0, query.n_edges, cap, pairs)
+    h.sort_pairs(pairs, n)
+    got = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
+    closest = h.alloc(4 * query.n_points)
+    faces = h.alloc(4 * query.n_points)
+    h.pip_query(0, 1, None, 0, query.n_points, closest, faces)
+    m0 = oracle.Map(base.pts, base.row_index, base.left, base.right)
+    m1 = oracle.Map(query.pts, query.row_index, query.left, query.right)
+    want = oracle.lsi_grid(m0, m1, 4096, cap=cap)
+    assert len(want) == n > 10000 and np.array_equal(want["eid"], got)
+    we = oracle.pip_grid(m0, 0, query.pts, 4096)
+    assert np.array_equal(we, closest.to_host(np.uint32))
+    assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
+    h.close()
