@@ -720,23 +720,12 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       if (STATS) tk_drain += clock64() - tk0;
     };
 
-    // a child survives only if SOME lane's upward ray can still hit it
-    auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
-      uint64_t keep = 0;
-      while (um) {
-        const int c = __builtin_ctzll(um);
-        um &= um - 1;
-        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
-        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        if (__ballot(ray_can_hit(qx, qym1, qbest, cx0, cy0, cx1, cy1))) keep |= 1ull << c;
-      }
-      return keep;
-    };
-
     int sp = 0;
     {
       QBox b = T.lvl[T.top][lane];
-      uint64_t m = refine(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
+      // (children are pushed on the cheap group-level test; the per-lane test happens when an entry
+      // is popped -- by then many have gone stale and die in the bulk sweep without costing a pop)
+      uint64_t m = __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1);
       const int n = __popcll(m);
       // reversed so that lane 0's child (lowest Morton = lowest y half) pops first
       if ((m >> lane) & 1)
@@ -763,7 +752,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       if (lvl > 1) {
         const long long tk0 = STATS ? clock64() : 0;
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
-        uint64_t m = refine(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
+        uint64_t m = __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest);
         const int n = __popcll(m);
         if ((m >> lane) & 1)
           L.stack[sp + n - 1 - rank_below(m)] =
