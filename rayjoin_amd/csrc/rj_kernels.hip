@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
-  unsigned long long st_stale = 0;
+  unsigned long long st_stale = 0, st_leaf_nocand = 0, st_leaf_lanes = 0;
   long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_rounds = 0, tk_sched = 0, tk_head = 0, tk_tail = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
@@ -771,6 +771,8 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         // (lanes whose ray cannot use this block any more, or never could, sit the visit out: `want`)
         const int ub = wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
         int j = want ? ub - 1 : -1;
+        const int cnt_before = cnt;
+        if (STATS) st_leaf_lanes += (unsigned long long) __popcll(__ballot(want));
         for (;;) {
           const int jj = j < 0 ? 0 : j;
           const int32_t pmj = __shfl(pm, jj, 64);
@@ -790,6 +792,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
           if (__ballot(cnt >= kPipList)) evaluate(false);
           j--;
         }
+        if (STATS && !__ballot(cnt != cnt_before)) st_leaf_nocand++;
         const int32_t gbest_before = gbest;
         gbest = wave_max(qbest);
         if (gbest < gbest_before && sp > 1) {
@@ -842,6 +845,8 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
     atomicAdd(&A.stats[11], (unsigned long long) tk_head);
     atomicAdd(&A.stats[12], (unsigned long long) tk_tail);
     atomicAdd(&A.stats[13], st_stale);
+    atomicAdd(&A.stats[14], st_leaf_nocand);
+    atomicAdd(&A.stats[15], st_leaf_lanes);
   }
 }
 
