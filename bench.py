@@ -58,6 +58,8 @@ def cpu_baseline(args, ctx):
     (same per-segment geometry, ~scale^2 of the segments).  Query time only, like the GPU side."""
     from oracle import rjoracle as O
     from rayjoin_amd import maps, synth
+    # all host cores this process may use, capped: the GPU box is shared
+    O.lib().rjo_set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
     if args.cpu_scale != 1.0:
         g0 = synth.standin(args.base, args.cpu_scale * args.scale)
         g1 = synth.standin(args.query, args.cpu_scale * args.scale)
