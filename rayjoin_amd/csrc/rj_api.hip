@@ -74,6 +74,9 @@ struct rj_handle_s {
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 4;      // consecutive 64-query groups handed to a wave at a time
   uint64_t last_stats[16] = {0};
+  // grow-only arena for the overlay pass (carved per call, no per-call hipMalloc/hipFree)
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   unsigned long long* d_counts = nullptr;  // [nranks] gathered counts
@@ -181,6 +184,7 @@ int rj_destroy(rj_handle h) {
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
+  (void) hipFree(h->arena);
   if (h->comm) (void) ncclCommDestroy(h->comm);
   (void) hipFree(h->d_counts);
   (void) hipStreamDestroy(h->own_stream);
@@ -659,29 +663,36 @@ int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint6
   if (n == 0) return RJ_OK;
   if (n >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: too many intersections");
   if (int r = set_device(h)) return r;
-  XsectRec* tmp = nullptr;
-  uint64_t *kin = nullptr, *kout = nullptr;
-  uint32_t *vin = nullptr, *vout = nullptr, *closest = nullptr;
-  int32_t* face = nullptr;
-  int64_t* mid = nullptr;
-  void* temp = nullptr;
-  size_t temp_bytes = 0;
+  // carve all temporaries out of one grow-only arena
+  auto up = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+  size_t sort_bytes = 0;
+  RJ_HIP(h, sort_pairs_u64_u32(h->stream, nullptr, sort_bytes, (const uint64_t*) nullptr, (uint64_t*) nullptr,
+                              (const uint32_t*) nullptr, (uint32_t*) nullptr, n));
+  const size_t need = up(48 * n) + 2 * up(8 * n) + 4 * up(4 * n) + up(16 * n) + up(sort_bytes);
+  if (need > h->arena_bytes) {
+    (void) hipFree(h->arena);
+    h->arena = nullptr; h->arena_bytes = 0;
+    RJ_HIP(h, hipMalloc((void**) &h->arena, need));
+    h->arena_bytes = need;
+  }
+  char* p = h->arena;
+  auto take = [&](size_t bytes) { char* r = p; p += up(bytes); return r; };
+  XsectRec* tmp = (XsectRec*) take(48 * n);
+  uint64_t* kin = (uint64_t*) take(8 * n);
+  uint64_t* kout = (uint64_t*) take(8 * n);
+  uint32_t* vin = (uint32_t*) take(4 * n);
+  uint32_t* vout = (uint32_t*) take(4 * n);
+  uint32_t* closest = (uint32_t*) take(4 * n);
+  int32_t* face = (int32_t*) take(4 * n);
+  int64_t* mid = (int64_t*) take(16 * n);
+  void* temp = take(sort_bytes);
+  size_t temp_bytes = sort_bytes;
   int rc = RJ_OK;
   hipError_t e = hipSuccess;
   do {
-    if ((rc = dev_alloc(h, &tmp, n))) break;
-    if ((rc = dev_alloc(h, &kin, n))) break;
-    if ((rc = dev_alloc(h, &kout, n))) break;
-    if ((rc = dev_alloc(h, &vin, n))) break;
-    if ((rc = dev_alloc(h, &vout, n))) break;
-    if ((rc = dev_alloc(h, &closest, n))) break;
-    if ((rc = dev_alloc(h, &face, n))) break;
-    if ((rc = dev_alloc(h, &mid, 2 * n))) break;
     // 1. the 48-byte records  2. order by (eid[im], eid[1-im])  3. per-edge order by distance, mid-points
     if ((e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, tmp)) != hipSuccess) break;
     if ((e = launch_xsect_keys(h->stream, tmp, n, im, kin, vin)) != hipSuccess) break;
-    if ((e = sort_pairs_u64_u32(h->stream, nullptr, temp_bytes, kin, kout, vin, vout, n)) != hipSuccess) break;
-    if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1)) != hipSuccess) break;
     if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, kin, kout, vin, vout, n)) != hipSuccess) break;
     if ((e = launch_xsect_gather(h->stream, tmp, vout, n, (XsectRec*) xsects_dev)) != hipSuccess) break;
     if ((e = launch_xsect_order_runs(h->stream, (XsectRec*) xsects_dev, n, im, h->map[im].seg, mid)) != hipSuccess) break;
@@ -690,8 +701,6 @@ int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint6
     if ((e = launch_xsect_set_mid(h->stream, (XsectRec*) xsects_dev, n, im, face)) != hipSuccess) break;
     e = hipStreamSynchronize(h->stream);
   } while (0);
-  (void) hipFree(tmp); (void) hipFree(kin); (void) hipFree(kout); (void) hipFree(vin); (void) hipFree(vout);
-  (void) hipFree(closest); (void) hipFree(face); (void) hipFree(mid); (void) hipFree(temp);
   if (rc) return rc;
   RJ_HIP(h, e);
   return RJ_OK;

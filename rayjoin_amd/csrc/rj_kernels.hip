@@ -626,6 +626,7 @@ __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, u
 //     points) or relevant points (lanes = base segments).
 // =============================================================================================
 constexpr int kPipList = 8;     // candidate slots per lane between two exact-evaluation rounds
+constexpr int kPipRefineAbove = 16;  // per-lane check at push time only when more children than this pass the group test
 constexpr int kPipStack = 64 * 4;  // >= 63 * (levels - 1) + 64 entries for <= 4 expanded levels
 
 // A stack entry carries the node's y0 and x-range, so a stale entry (every lane under it has since
@@ -720,12 +721,26 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       if (STATS) tk_drain += clock64() - tk0;
     };
 
+    // Children are normally pushed on the cheap group-level test alone: the per-lane test happens
+    // when an entry is popped, and by then many have gone stale and die in the bulk sweep without
+    // costing a pop.  Only when the group test lets MANY children through (a sparse or scattered
+    // group whose box covers far more than its points) is each one checked against the lanes first.
+    auto refine_if_many = [&](const QBox& b, uint64_t um) -> uint64_t {
+      if (__popcll(um) <= kPipRefineAbove) return um;
+      uint64_t keep = 0;
+      while (um) {
+        const int c = __builtin_ctzll(um);
+        um &= um - 1;
+        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
+        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
+        if (__ballot(ray_can_hit(qx, qym1, qbest, cx0, cy0, cx1, cy1))) keep |= 1ull << c;
+      }
+      return keep;
+    };
     int sp = 0;
     {
       QBox b = T.lvl[T.top][lane];
-      // (children are pushed on the cheap group-level test; the per-lane test happens when an entry
-      // is popped -- by then many have gone stale and die in the bulk sweep without costing a pop)
-      uint64_t m = __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1);
+      uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
       const int n = __popcll(m);
       // reversed so that lane 0's child (lowest Morton = lowest y half) pops first
       if ((m >> lane) & 1)
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
       if (lvl > 1) {
         const long long tk0 = STATS ? clock64() : 0;
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
-        uint64_t m = __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest);
+        uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
         const int n = __popcll(m);
         if ((m >> lane) & 1)
           L.stack[sp + n - 1 - rank_below(m)] =
