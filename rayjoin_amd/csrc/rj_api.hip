@@ -72,7 +72,8 @@ struct rj_handle_s {
   void* ord_temp = nullptr;
   size_t ord_temp_bytes = 0;
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
-  int chunk_groups = 4;      // consecutive 64-query groups handed to a wave at a time
+  int chunk_groups = 4;      // consecutive groups handed to a wave at a time
+  int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
   uint64_t last_stats[16] = {0};
   // grow-only arena for the overlay pass (carved per call, no per-call hipMalloc/hipFree)
   char* arena = nullptr;
@@ -215,6 +216,12 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "query_order")) {
     if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "query_order: 0 never, 1 auto, 2 always");
     h->query_order = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "group_lanes")) {
+    if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
+      return fail(h, RJ_E_INVALID, "group_lanes: 0 (auto), 4, 8, 16, 32 or 64");
+    h->group_lanes = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "chunk_groups")) {
@@ -441,6 +448,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.counter = h->d_counter;
   a.work_counter = (unsigned int*) (h->d_counter + 16);
   a.chunk_groups = (uint32_t) h->chunk_groups;
+  a.group_lanes = (uint32_t) h->group_lanes;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_LSI_KERNEL);
   if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, h->max_blocks));
@@ -541,6 +549,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.closest = closest_eid_dev; a.face = face_id_dev;
   a.work_counter = (unsigned int*) (h->d_counter + 16);
   a.chunk_groups = (uint32_t) h->chunk_groups;
+  a.group_lanes = (uint32_t) h->group_lanes;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_PIP_KERNEL);
   if (n) RJ_HIP(h, launch_pip(h->stream, a, h->stats_on, h->max_blocks));

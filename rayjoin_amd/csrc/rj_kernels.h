@@ -22,7 +22,8 @@ struct LsiArgs {
   uint64_t cap;
   unsigned long long* counter;  // result count
   unsigned int* work_counter;   // dynamic chunk scheduler (zeroed before every launch)
-  uint32_t chunk_groups;        // consecutive 64-query groups per chunk
+  uint32_t chunk_groups;        // consecutive groups per chunk
+  uint32_t group_lanes;         // queries per wave (0 = choose from the query count)
   unsigned long long* stats;    // [4] or nullptr
 };
 
@@ -37,6 +38,7 @@ struct PipArgs {
   int32_t* face;       // [n] or nullptr
   unsigned int* work_counter;
   uint32_t chunk_groups;
+  uint32_t group_lanes;  // points per wave (0 = choose from the point count)
   unsigned long long* stats;
 };
 

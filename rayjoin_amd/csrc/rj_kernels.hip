@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
   const int wib = threadIdx.x >> 6;
   LsiWaveLds& L = lds[wib];
   const uint64_t nq = A.qend - A.qbeg;
-  const uint64_t ngroups = (nq + 63) >> 6;
+  const uint32_t GL = A.group_lanes;  // queries per wave: 64, or fewer for small query sets (more waves, shorter chains)
+  const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
@@ -379,8 +380,8 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
   const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
   for (uint64_t g = g_begin; g < g_end; g++) {
     const long long tkg = STATS ? clock64() : 0;
-    const uint64_t qi = g * 64 + lane;  // position in the (possibly Morton-sorted) query order
-    const bool valid = qi < nq;
+    const uint64_t qi = g * GL + lane;  // position in the (possibly Morton-sorted) query order
+    const bool valid = (uint32_t) lane < GL && qi < nq;
     const uint64_t q = A.qbeg + (A.order ? (valid ? A.order[qi] : 0) : qi);
     int32_t qx0 = kEmptyMin, qy0 = kEmptyMin, qx1 = kEmptyMax, qy1 = kEmptyMax;
     if (valid) {
@@ -642,7 +643,8 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   PipWaveLds& L = lds[wib];
-  const uint64_t ngroups = (A.n + 63) >> 6;
+  const uint32_t GL = A.group_lanes;  // points per wave: 64, or fewer for small query sets
+  const uint64_t ngroups = (A.n + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
@@ -661,8 +663,8 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
   const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
   for (uint64_t g = g_begin; g < g_end; g++) {
     const long long tkg = STATS ? clock64() : 0;
-    const uint64_t ipos = g * 64 + lane;  // position in the (possibly Morton-sorted) query order
-    const bool valid = ipos < A.n;
+    const uint64_t ipos = g * GL + lane;  // position in the (possibly Morton-sorted) query order
+    const bool valid = (uint32_t) lane < GL && ipos < A.n;
     const uint64_t ip = A.order ? (valid ? A.order[ipos] : 0) : ipos;
     int64_t px = 0, py = 0;
     if (valid) {
@@ -956,12 +958,24 @@ static int resident_blocks(const void* kernel, int max_blocks) {
   return b < max_blocks ? b : max_blocks;
 }
 
-hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks) {
-  uint64_t ngroups = (a.qend - a.qbeg + 63) / 64;
-  uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+// Small query sets: with 64 queries per wave there are fewer groups than resident waves and each
+// wave walks a long serial chain of node visits.  Fewer queries per wave spread the same visits
+// over more waves (the kernels are latency-bound, idle lanes cost nothing).
+static uint32_t pick_group_lanes(uint64_t nqueries, int resident_blocks_) {
+  const uint64_t waves = (uint64_t) resident_blocks_ * 4;
+  uint32_t gl = 64;
+  while (gl > 4 && (nqueries + gl - 1) / gl < 2 * waves) gl >>= 1;
+  return gl;
+}
+
+hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_blocks) {
+  LsiArgs a = a_in;
   const void* k = stats ? (const void*) k_lsi<true> : (const void*) k_lsi<false>;
   static int res[2] = {0, 0};
   if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
+  if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.qend - a.qbeg, res[stats]);
+  uint64_t ngroups = (a.qend - a.qbeg + a.group_lanes - 1) / a.group_lanes;
+  uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
     hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a);
@@ -999,12 +1013,14 @@ hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, c
   return hipGetLastError();
 }
 
-hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks) {
-  uint64_t ngroups = (a.n + 63) / 64;
-  uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+hipError_t launch_pip(hipStream_t st, const PipArgs& a_in, bool stats, int max_blocks) {
+  PipArgs a = a_in;
   const void* k = stats ? (const void*) k_pip<true> : (const void*) k_pip<false>;
   static int res[2] = {0, 0};
   if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
+  if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.n, res[stats]);
+  uint64_t ngroups = (a.n + a.group_lanes - 1) / a.group_lanes;
+  uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
     hipLaunchKernelGGL(k_pip<true>, dim3(grid), dim3(256), 0, st, a);
