@@ -173,7 +173,9 @@ int rj_last_ms(rj_handle h, int which, float* ms);
  * build (total, node expansion, leaf loop, dense predicate phase, merge rounds, max wave total).
  * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
 int rj_last_stats(rj_handle h, uint64_t stats[16]);
-/* options: "stats" 0/1; "chunk_groups" n; "max_blocks" n; "own_stream" 1;
+/* options: "stats" 0/1 (instrumented kernels); "chunk_groups" n (consecutive groups handed to a
+ * wave at a time, default 4); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
+ * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
  * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
  * consecutive queries are spatially scattered, e.g. the generated workloads of
  * src/run_query.cu:102-167) / 2 always. */

@@ -1,0 +1,31 @@
+"""The bench line committed under profiles/ carries every field of the bench contract."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
+    assert all(d["checks"].values())
+    # value is whole-step throughput of the query map's segments
+    n_s = 28793160
+    assert abs(d["value"] - n_s / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+def test_traffic_file_matches_the_kernels_bench_reports():
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert set(t) == {"k_lsi", "k_pip"} and all(v > 0 for v in t.values())
