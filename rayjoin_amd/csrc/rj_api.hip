@@ -331,7 +331,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   if (int r = dev_alloc(h, &b.sface, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.box0, b.n0p)) return r;
   if (int r = dev_alloc(h, &b.pmx1, b.n0p)) return r;
-  if (int r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords)) return r;
+  if (int r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1)) return r;
   for (int l = 1; l <= top; l++)
     if (int r = dev_alloc(h, &b.lvl[l], b.alloc[l])) return r;
   // 1. Morton keys  2. radix sort (key, eid)  3. gather into sorted order + leaf boxes  4. levels
@@ -353,7 +353,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
     }
     if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p, b.sseg, b.seid, b.sface, b.box0)) != hipSuccess) break;
-    if ((e = hipMemsetAsync(b.occ, 0, (size_t) kOccDim * kOccRowWords * 4, h->stream)) != hipSuccess) break;
+    if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
     if ((e = launch_mark_occupancy(h->stream, b.box0, b.n0p, b.occ)) != hipSuccess) break;
     if ((e = launch_sort_leaf_blocks(h->stream, b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.n0p / 64)) != hipSuccess) break;
     const QBox* child = b.box0;

@@ -28,6 +28,7 @@ constexpr int64_t kCoordOffset = (int64_t) 1 << 46;
 constexpr int kOccShift = 19;                  // 31-bit quantised coordinate -> 12-bit cell
 constexpr int kOccDim = 1 << (31 - kOccShift);  // 4096 x 4096 cells = 2 MiB of bits
 constexpr int kOccRowWords = kOccDim / 32;
+constexpr int kOccMaxCellsPerSeg = 4096;  // larger boxes are not rasterised; word [kOccDim*kOccRowWords] flags that
 constexpr int32_t kEmptyMin = 0x7FFFFFFF;
 constexpr int32_t kEmptyMax = -1;
 

@@ -109,6 +109,13 @@ __global__ __launch_bounds__(256) void k_mark_occupancy(const QBox* __restrict__
     if (b.x1 < b.x0) continue;  // padding
     const int cx0 = b.x0 >> kOccShift, cx1 = b.x1 >> kOccShift;
     const int cy0 = b.y0 >> kOccShift, cy1 = b.y1 >> kOccShift;
+    if ((int64_t) (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > kOccMaxCellsPerSeg) {
+      // a segment whose box covers a large part of the map: rasterising its box would cost up to
+      // 512 k atomics per segment; raise the "bitmap not exhaustive" word instead (the LSI kernel
+      // then skips the pre-filter -- a performance hint, never a correctness input)
+      atomicOr(&occ[(size_t) kOccDim * kOccRowWords], 1u);
+      continue;
+    }
     for (int cy = cy0; cy <= cy1; cy++)
       for (int w = cx0 >> 5; w <= (cx1 >> 5); w++) {
         const int lo = w == (cx0 >> 5) ? (cx0 & 31) : 0;
@@ -361,6 +368,7 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
   const uint32_t GL = A.group_lanes;  // queries per wave: 64, or fewer for small query sets (more waves, shorter chains)
   const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
+  const bool occ_usable = T.occ[(size_t) kOccDim * kOccRowWords] == 0;  // every base segment was rasterised
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
   long long tk_node = 0, tk_leaf = 0, tk_head = 0, tk_sched = 0;  // STATS: cycle stamps
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
       qx1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
       qy0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
       qy1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
-      if (!occ_any(T.occ, qx0, qy0, qx1, qy1)) {  // nothing of the base map near this segment
+      if (occ_usable && !occ_any(T.occ, qx0, qy0, qx1, qy1)) {  // nothing of the base map near this segment
         qx0 = kEmptyMin; qy0 = kEmptyMin; qx1 = kEmptyMax; qy1 = kEmptyMax;
       }
     }

@@ -283,3 +283,35 @@ def test_medium_maps_against_grid_oracle(oracle):
     assert np.array_equal(pip.get_closest_eids(), want)
     assert np.array_equal(pip.get_face_ids(), m0.face_ids(want))
     dctx.close()
+
+
+def test_domain_spanning_segments(oracle):
+    """A few base segments as long as the map (boxes covering millions of bitmap cells) among many
+    small ones: the occupancy bitmap is flagged non-exhaustive instead of being rasterised for
+    them, results stay exact, and the build stays fast."""
+    import time
+    rng = np.random.default_rng(8)
+    small = synth.adversarial_segments(4000, 1 << 30, 81)
+    big = np.array([[-(1 << 45), -(1 << 45) + 7, (1 << 45), (1 << 45) - 3],
+                    [-(1 << 45), (1 << 44), (1 << 45), -(1 << 44)],
+                    [5, -(1 << 45), 9, (1 << 45)]], dtype=np.int64).reshape(-1, 2)
+    a = np.concatenate([small, big])
+    b = synth.adversarial_segments(5000, 1 << 30, 82)
+    ctx = maps.Context([None, None])
+    ctx.maps = [maps.ScaledMap.from_segments(0, a), maps.ScaledMap.from_segments(1, b)]
+    dctx = ops.DeviceContext(ctx).LoadToDevice()
+    t0 = time.perf_counter()
+    dctx.BuildIndex(0)
+    dctx.BuildIndex(1)
+    assert time.perf_counter() - t0 < 2.0
+    o0, o1 = oracle.Map(a), oracle.Map(b)
+    want = oracle.lsi_brute(o0, o1)
+    assert len(want) > 1000
+    for qm in (1, 0):
+        assert np.array_equal(_lsi(dctx, qm, 4 * len(want)).get_pairs(), want)
+    pts = rng.integers(-(1 << 30), 1 << 30, size=(4000, 2))
+    pip = ops.PIPLBVH(dctx)
+    pip.Init(len(pts))
+    pip.Query(1, query_points=pts)
+    assert np.array_equal(pip.get_closest_eids(), oracle.pip_brute(o0, 1, pts))
+    dctx.close()
