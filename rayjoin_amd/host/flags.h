@@ -26,6 +26,7 @@ struct Flags {
   int device = 0;  // ours: GPU ordinal
   int nranks = 1, rank = 0;  // ours: one process per GPU; the query map is sharded by chain range
   std::string comm_file;     // ours: rank 0 writes the RCCL unique id here, the others read it
+  std::string sample_output; // ours: write the sampled map (-sample) as a .bin cache file, for inspection/tests
 
   static bool parse_bool(const std::string& s) {
     if (s == "" || s == "1" || s == "true" || s == "t" || s == "yes" || s == "y") return true;
@@ -42,7 +43,7 @@ struct Flags {
     RJ_S(poly1) RJ_S(poly2) RJ_S(output) RJ_S(mode) RJ_S(serialize) RJ_S(sample) RJ_S(query)
     RJ_I(grid_size) RJ_D(xsect_factor) RJ_B(box) RJ_B(check) RJ_B(fau) RJ_I(warmup) RJ_I(repeat)
     RJ_I(ag) RJ_I(ag_iter) RJ_I(win) RJ_D(enlarge) RJ_I(sample_map_id) RJ_D(sample_rate)
-    RJ_I(seed) RJ_D(gen_t) RJ_I(gen_n) RJ_B(histo) RJ_B(profile) RJ_I(v) RJ_I(device) RJ_I(nranks) RJ_I(rank) RJ_S(comm_file)
+    RJ_I(seed) RJ_D(gen_t) RJ_I(gen_n) RJ_B(histo) RJ_B(profile) RJ_I(v) RJ_I(device) RJ_I(nranks) RJ_I(rank) RJ_S(comm_file) RJ_S(sample_output)
 #undef RJ_S
 #undef RJ_I
 #undef RJ_D

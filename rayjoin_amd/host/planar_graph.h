@@ -17,6 +17,8 @@
 #include <limits>
 #include <memory>
 #include <numeric>
+#include <map>
+#include <random>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -141,6 +143,82 @@ inline std::shared_ptr<PlanarGraph> load_from(const std::string& path, const std
   auto pg = read_pgraph(path.c_str(), verbose);
   if (!serialize_prefix.empty() && access(serialize_prefix.c_str(), W_OK) == 0) serialize_pgraph(*pg, ser.c_str());
   return pg;
+}
+
+// Samplers of the paper's scalability runs (planar_graph.h:255-399; flags -sample, -sample_map_id,
+// -sample_rate, -seed).  Both use std::mt19937 + std::shuffle like the reference, so with the same
+// libstdc++ and a non-zero seed the sampled map is the same one.
+namespace detail {
+inline void append_points(PlanarGraph& out, const PlanarGraph& in, const std::vector<size_t>& pids) {
+  out.row_index.push_back((uint32_t) out.points.size());
+  for (size_t pid : pids) {
+    const Point2d& p = in.points[pid];
+    out.points.push_back(p);
+    out.bb.min_x = std::min(out.bb.min_x, p.x);
+    out.bb.max_x = std::max(out.bb.max_x, p.x);
+    out.bb.min_y = std::min(out.bb.min_y, p.y);
+    out.bb.max_y = std::max(out.bb.max_y, p.y);
+  }
+}
+}  // namespace detail
+
+// "-sample map": every chain survives with its two end points; of its interior points a random
+// sample_rate fraction (at least one) is kept, in the original order -- a down-scaled map with the
+// original topology.
+inline std::shared_ptr<PlanarGraph> sample_map_from(const PlanarGraph& g, float sample_rate, int seed = 0) {
+  std::random_device rd;
+  std::mt19937 gen(seed == 0 ? rd() : seed);
+  auto out = std::make_shared<PlanarGraph>();
+  out->chains = g.chains;
+  std::vector<size_t> pids;
+  for (size_t ic = 0; ic < g.chains.size(); ic++) {
+    const size_t begin = g.row_index[ic], end = g.row_index[ic + 1];
+    pids.assign(1, begin);
+    if (end - begin > 2) {
+      for (size_t pid = begin + 1; pid + 1 < end; pid++) pids.push_back(pid);
+      std::shuffle(pids.begin() + 1, pids.end(), gen);
+      pids.resize(std::max((size_t) 2, (size_t) (pids.size() * sample_rate)));
+      std::sort(pids.begin() + 1, pids.end());
+    }
+    pids.push_back(end - 1);
+    detail::append_points(*out, g, pids);
+  }
+  if (!out->points.empty()) out->row_index.push_back((uint32_t) out->points.size());
+  return out;
+}
+
+// "-sample edges": a random sample_rate fraction of all edges; the surviving edges of a chain are
+// re-packed into one chain (consecutive survivors stay connected, gaps are bridged by the chain's
+// next surviving point), chains without survivors disappear and chain ids are renumbered from 0.
+inline std::shared_ptr<PlanarGraph> sample_edges_from(const PlanarGraph& g, float sample_rate, int seed = 0) {
+  std::vector<std::pair<size_t, size_t>> edges;  // (chain, first point of the edge)
+  edges.reserve(g.points.size());
+  for (size_t ic = 0; ic < g.chains.size(); ic++)
+    for (size_t pid = g.row_index[ic]; pid + 1 < g.row_index[ic + 1]; pid++) edges.emplace_back(ic, pid);
+  std::random_device rd;
+  std::mt19937 gen(seed == 0 ? rd() : seed);
+  std::shuffle(edges.begin(), edges.end(), gen);
+  edges.resize((size_t) (edges.size() * sample_rate));
+  std::map<size_t, std::vector<size_t>> by_chain;
+  for (const auto& e : edges) by_chain[e.first].push_back(e.second);
+  auto out = std::make_shared<PlanarGraph>();
+  int64_t chain_id = 0;
+  std::vector<size_t> pids;
+  for (const auto& kv : by_chain) {
+    Chain c = g.chains[kv.first];
+    c.id = chain_id++;
+    out->chains.push_back(c);
+    pids.clear();
+    for (size_t p1 : kv.second) {
+      pids.push_back(p1);
+      pids.push_back(p1 + 1);
+    }
+    std::sort(pids.begin(), pids.end());
+    pids.erase(std::unique(pids.begin(), pids.end()), pids.end());
+    detail::append_points(*out, g, pids);
+  }
+  if (!out->points.empty()) out->row_index.push_back((uint32_t) out->points.size());
+  return out;
 }
 
 }  // namespace rayjoin

@@ -23,7 +23,8 @@ namespace {
 void Usage(const char* argv0) {
   std::cerr << "Usage: " << argv0 << " -poly1 <base.cdb> [-poly2 <query.cdb>] -query lsi|pip -mode lbvh\n"
             << "  [-serialize <dir>] [-xsect_factor 0.2] [-warmup 5] [-repeat 5] [-seed N] [-gen_n 10000]\n"
-            << "  [-gen_t 0.1] [-output <pairs.txt>] [-device 0] [-v 1]\n";
+            << "  [-gen_t 0.1] [-output <pairs.txt>] [-device 0] [-v 1]\n"
+            << "  [-sample map|edges -sample_map_id 0|1 -sample_rate 0.5 [-sample_output <map.bin>]]\n";
 }
 
 // GenerateLSIQueries (run_query.cu:102-144)
@@ -84,6 +85,23 @@ void InitComm(const Flags& f, Context& ctx) {
   rj_check(ctx.handle(), rj_comm_init(ctx.handle(), f.nranks, f.rank, id), "rj_comm_init");
 }
 
+// -sample map|edges -sample_map_id 0|1 -sample_rate r -seed s (src/flags.cc:20-27): thin out one of
+// the two input maps before anything is scaled or uploaded (the paper's scalability runs).
+void ApplySampling(const Flags& f, std::shared_ptr<PlanarGraph>& base, std::shared_ptr<PlanarGraph>* query) {
+  if (f.sample.empty()) return;
+  if (f.sample != "map" && f.sample != "edges") throw std::invalid_argument("Invalid sample option: " + f.sample + " (map|edges)");
+  if (f.sample_map_id != 0 && f.sample_map_id != 1) throw std::invalid_argument("-sample needs -sample_map_id 0|1");
+  if (!(f.sample_rate > 0 && f.sample_rate <= 1)) throw std::invalid_argument("-sample_rate must be in (0, 1]");
+  std::shared_ptr<PlanarGraph>* target = f.sample_map_id == 0 ? &base : query;
+  if (!target || !*target) throw std::invalid_argument("-sample_map_id 1 needs -poly2");
+  *target = f.sample == "map" ? sample_map_from(**target, (float) f.sample_rate, f.seed)
+                              : sample_edges_from(**target, (float) f.sample_rate, f.seed);
+  if (f.v >= 1)
+    std::cerr << (f.sample == "map" ? "Map is sampled" : "Edges are sampled") << ", chains: " << (*target)->chains.size()
+              << " points: " << (*target)->points.size() << " edges: " << (*target)->n_edges() << "\n";
+  if (!f.sample_output.empty()) serialize_pgraph(**target, f.sample_output.c_str());
+}
+
 void CheckMode(const Flags& f) {
   if (f.mode == "lbvh") return;
   if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
@@ -99,12 +117,14 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
   std::unique_ptr<Context> ctx;
   std::shared_ptr<HostMap> gen_queries;
   if (f.poly2.empty()) {
+    ApplySampling(f, base, nullptr);
     tm.next("Generate Workloads");
     ctx.reset(new Context({base, nullptr}, f.device));
     gen_queries = GenerateLSIQueries(f, *ctx);
   } else {
     tm.next("Read map 1");
     auto query = load_from(f.poly2, f.serialize, f.v);
+    ApplySampling(f, base, &query);
     ctx.reset(new Context({base, query}, f.device));
   }
   tm.next("Create App");
@@ -165,6 +185,7 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   int64_t* d_pts = nullptr;
   size_t n_points = 0;
   if (f.poly2.empty()) {
+    ApplySampling(f, base, nullptr);
     tm.next("Generate Workloads");
     ctx.reset(new Context({base, nullptr}, f.device));
     gen_pts = GeneratePIPQueries(f, *ctx);
@@ -176,6 +197,7 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   } else {
     tm.next("Read map 1");
     auto query = load_from(f.poly2, f.serialize, f.v);
+    ApplySampling(f, base, &query);
     ctx.reset(new Context({base, query}, f.device));
     tm.next("Load Data");
     ctx->LoadToDevice();

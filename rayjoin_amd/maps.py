@@ -155,6 +155,48 @@ def load_from(path, serialize_prefix=""):
     return g
 
 
+def sample_map_from(g, sample_rate, seed=0):
+    """planar_graph.h:255-317 ("-sample map"): keep every chain and its two end points; of the
+    interior points keep a random fraction (at least one), in order.  Same semantics as the C++
+    host's sampler, numpy's generator instead of std::mt19937 (a different but equally valid draw)."""
+    rng = np.random.default_rng(None if seed == 0 else seed)
+    keep = []
+    row = [0]
+    for ic in range(g.n_chains):
+        b, e = int(g.row_index[ic]), int(g.row_index[ic + 1])
+        pids = [b]
+        if e - b > 2:
+            mid = rng.permutation(np.arange(b + 1, e - 1))
+            n_keep = max(2, int((1 + len(mid)) * np.float32(sample_rate)))  # counts the first point too
+            pids += sorted(int(v) for v in mid[:n_keep - 1])
+        pids.append(e - 1)
+        keep += pids
+        row.append(len(keep))
+    return PlanarGraph(g.chains.copy(), np.array(row, dtype=np.uint32), g.points[keep])
+
+
+def sample_edges_from(g, sample_rate, seed=0):
+    """planar_graph.h:319-399 ("-sample edges"): a random fraction of all edges; survivors of one
+    chain are re-packed into one chain, empty chains vanish, chain ids are renumbered from 0."""
+    rng = np.random.default_rng(None if seed == 0 else seed)
+    chain_of = np.repeat(np.arange(g.n_chains), np.diff(g.row_index.astype(np.int64)) - 1)
+    first_pid = np.concatenate([np.arange(int(g.row_index[ic]), int(g.row_index[ic + 1]) - 1)
+                                for ic in range(g.n_chains)]) if g.n_chains else np.zeros(0, np.int64)
+    pick = rng.permutation(len(first_pid))[:int(len(first_pid) * np.float32(sample_rate))]
+    chains, keep, row = [], [], [0]
+    for new_id, ic in enumerate(np.unique(chain_of[pick])):
+        p1 = first_pid[pick[chain_of[pick] == ic]]
+        pids = np.unique(np.concatenate([p1, p1 + 1]))
+        c = g.chains[ic].copy()
+        c[0] = new_id
+        chains.append(c)
+        keep += [int(v) for v in pids]
+        row.append(len(keep))
+    if not chains:
+        return PlanarGraph(np.zeros((0, 5), np.int64), np.zeros(0, np.uint32), np.zeros((0, 2)))
+    return PlanarGraph(np.array(chains), np.array(row, dtype=np.uint32), g.points[keep])
+
+
 class Scaling:
     """Scaling<double, int64_t, 17> (scaling.h:32-136)."""
 

@@ -79,3 +79,57 @@ def test_bin_cache_cpp_python_compatible(exe, tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert r.returncode == 3 and "rj_create failed" in r.stderr  # loud, no fallback
+
+
+def _check_map_sample(g, s, rate):
+    assert np.array_equal(s.chains, g.chains)  # every chain survives (topology preserved)
+    for ic in range(g.n_chains):
+        b, e = int(g.row_index[ic]), int(g.row_index[ic + 1])
+        sb, se = int(s.row_index[ic]), int(s.row_index[ic + 1])
+        want = e - b if e - b <= 2 else max(2, int((e - b - 1) * np.float32(rate))) + 1
+        assert se - sb == want
+        assert np.array_equal(s.points[sb], g.points[b]) and np.array_equal(s.points[se - 1], g.points[e - 1])
+        # an ordered subsequence of the original chain
+        orig = {tuple(p): k for k, p in enumerate(g.points[b:e])}
+        idx = [orig[tuple(p)] for p in s.points[sb:se]]
+        assert idx == sorted(set(idx))
+
+
+def _check_edge_sample(g, s, rate):
+    assert s.n_chains <= g.n_chains and list(s.chains[:, 0]) == list(range(s.n_chains))
+    n_picked = int(g.n_edges * np.float32(rate))
+    assert n_picked / 2 <= s.n_edges <= 2 * n_picked  # re-packing bridges gaps inside a chain
+    allp = {tuple(p) for p in g.points}
+    assert all(tuple(p) in allp for p in s.points)
+    by_lr = {(int(c[3]), int(c[4])) for c in g.chains}
+    assert all((int(c[3]), int(c[4])) in by_lr for c in s.chains)
+
+
+@pytest.mark.parametrize("kind", ["map", "edges"])
+def test_samplers(exe, tmp_path, kind):
+    """-sample map|edges (planar_graph.h:255-399): C++ host (std::mt19937, like the reference) and
+    Python host obey the same rules; the C++ draw is reproducible for a fixed -seed."""
+    g = maps.read_cdb(_write(tmp_path, synth.lattice_map(5, 9, 13)))
+    check = _check_map_sample if kind == "map" else _check_edge_sample
+    py = (maps.sample_map_from if kind == "map" else maps.sample_edges_from)(g, 0.4, seed=5)
+    check(g, py, 0.4)
+    outs = []
+    for rep in range(2):
+        out = str(tmp_path / ("s%d.bin" % rep))
+        r = subprocess.run([exe, "-poly1", str(tmp_path / "m.cdb"), "-query", "pip", "-mode", "lbvh", "-sample", kind,
+                            "-sample_map_id", "0", "-sample_rate", "0.4", "-seed", "5", "-sample_output", out,
+                            "-v", "1", "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)
+        assert os.path.exists(out), r.stderr
+        assert ("Map is sampled" if kind == "map" else "Edges are sampled") in r.stderr
+        outs.append(open(out, "rb").read())
+        check(g, maps.deserialize_bin(out), 0.4)
+    assert outs[0] == outs[1]
+    r = subprocess.run([exe, "-poly1", str(tmp_path / "m.cdb"), "-query", "pip", "-mode", "lbvh", "-sample", "bogus",
+                        "-sample_map_id", "0"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Invalid sample option" in r.stderr
+
+
+def _write(tmp_path, g):
+    p = str(tmp_path / "m.cdb")
+    maps.write_cdb(p, g, "%.9f")
+    return p
