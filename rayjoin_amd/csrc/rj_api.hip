@@ -301,6 +301,30 @@ int rj_map_points_dev(rj_handle h, int map_id, const int64_t** pts_dev) {
   return RJ_OK;
 }
 
+// Sort scratch ((u64 key, u32 value) in/out + rocPRIM temp) shared by the index build and the
+// query re-ordering; it only grows and stays with the handle, so a rebuild or a repeated query
+// does not pay hipMalloc again (24 B per item + temp; 2.4 GB for the 67 M-segment map).
+static int ensure_sort_scratch(rj_handle h, uint64_t n) {
+  if (n > h->ord_cap) {
+    (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout);
+    h->ord_kin = h->ord_kout = nullptr; h->ord_vin = h->ord_vout = nullptr; h->ord_cap = 0;
+    if (int r = dev_alloc(h, &h->ord_kin, n)) return r;
+    if (int r = dev_alloc(h, &h->ord_kout, n)) return r;
+    if (int r = dev_alloc(h, &h->ord_vin, n)) return r;
+    if (int r = dev_alloc(h, &h->ord_vout, n)) return r;
+    h->ord_cap = n;
+  }
+  size_t need = 0;
+  RJ_HIP(h, sort_pairs_u64_u32(h->stream, nullptr, need, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n, 0, 64 - kMortonDropBits));
+  if (need > h->ord_temp_bytes) {
+    (void) hipFree(h->ord_temp);
+    h->ord_temp = nullptr; h->ord_temp_bytes = 0;
+    RJ_HIP(h, hipMalloc(&h->ord_temp, need));
+    h->ord_temp_bytes = need;
+  }
+  return RJ_OK;
+}
+
 int rj_build_lbvh(rj_handle h, int base_map_id) {
   RJ_CHECK_H(h);
   if (base_map_id < 0 || base_map_id > 1 || !h->map[base_map_id].present)
@@ -308,7 +332,9 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   if (int r = set_device(h)) return r;
   const MapState& m = h->map[base_map_id];
   BvhState& b = h->bvh[base_map_id];
-  free_bvh(b);
+  const bool reuse = b.sseg && b.n0p == pad64(m.ne ? m.ne : 1);  // rebuild of a same-sized map: keep the buffers
+  if (!reuse) free_bvh(b);
+  b.built = false;
   tic(h, RJ_T_BUILD);
   b.n0 = m.ne;
   b.n0p = pad64(m.ne ? m.ne : 1);
@@ -326,39 +352,35 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   }
   if (b.nlvl[top] > 64) return fail(h, RJ_E_INVALID, "too many segments for %d levels", kMaxLevels);
   b.top = top;
-  if (int r = dev_alloc(h, &b.sseg, b.n0p)) return r;
-  if (int r = dev_alloc(h, &b.seid, b.n0p)) return r;
-  if (int r = dev_alloc(h, &b.sface, b.n0p)) return r;
-  if (int r = dev_alloc(h, &b.box0, b.n0p)) return r;
-  if (int r = dev_alloc(h, &b.pmx1, b.n0p)) return r;
-  if (int r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1)) return r;
-  for (int l = 1; l <= top; l++)
-    if (int r = dev_alloc(h, &b.lvl[l], b.alloc[l])) return r;
-  // 1. Morton keys  2. radix sort (key, eid)  3. gather into sorted order + leaf boxes  4. levels
-  uint64_t *k_in = nullptr, *k_out = nullptr;
-  uint32_t *v_in = nullptr, *v_out = nullptr;
-  void* temp = nullptr;
-  size_t temp_bytes = 0;
-  int rc = RJ_OK;
+  if (!reuse) {
+    int r = 0;
+    if (!r) r = dev_alloc(h, &b.sseg, b.n0p);
+    if (!r) r = dev_alloc(h, &b.seid, b.n0p);
+    if (!r) r = dev_alloc(h, &b.sface, b.n0p);
+    if (!r) r = dev_alloc(h, &b.box0, b.n0p);
+    if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
+    if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
+    for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l]);
+    if (r) { free_bvh(b); return r; }
+  }
+  // 1. Morton keys  2. radix sort (key, eid)  3. leaves + occupancy + level 1 in one pass  4. upper levels
+  if (m.ne)
+    if (int r = ensure_sort_scratch(h, m.ne)) return r;
+  uint64_t *k_in = h->ord_kin, *k_out = h->ord_kout;
+  uint32_t *v_in = h->ord_vin, *v_out = h->ord_vout;
   hipError_t e = hipSuccess;
   do {
-    if ((rc = dev_alloc(h, &k_in, m.ne))) break;
-    if ((rc = dev_alloc(h, &k_out, m.ne))) break;
-    if ((rc = dev_alloc(h, &v_in, m.ne))) break;
-    if ((rc = dev_alloc(h, &v_out, m.ne))) break;
     if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
     if (m.ne) {
-      if ((e = sort_pairs_u64_u32(h->stream, nullptr, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
-      if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1)) != hipSuccess) break;
-      if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
+      size_t tb = h->ord_temp_bytes;
+      if ((e = sort_pairs_u64_u32(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, m.ne, 0, 64 - kMortonDropBits)) != hipSuccess) break;
     }
-    if ((e = launch_gather_sorted(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p, b.sseg, b.seid, b.sface, b.box0)) != hipSuccess) break;
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
-    if ((e = launch_mark_occupancy(h->stream, b.box0, b.n0p, b.occ)) != hipSuccess) break;
-    if ((e = launch_sort_leaf_blocks(h->stream, b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.n0p / 64)) != hipSuccess) break;
-    const QBox* child = b.box0;
-    uint64_t child_alloc = b.n0p;
-    for (int l = 1; l <= top; l++) {
+    if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p / 64, b.alloc[1],
+                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.lvl[1], b.occ)) != hipSuccess) break;
+    const QBox* child = b.lvl[1];
+    uint64_t child_alloc = b.alloc[1];
+    for (int l = 2; l <= top; l++) {
       if ((e = launch_reduce_level(h->stream, child, child_alloc, b.lvl[l], b.alloc[l])) != hipSuccess) break;
       child = b.lvl[l];
       child_alloc = b.alloc[l];
@@ -367,8 +389,6 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     toc(h, RJ_T_BUILD);
     e = hipStreamSynchronize(h->stream);
   } while (0);
-  (void) hipFree(k_in); (void) hipFree(k_out); (void) hipFree(v_in); (void) hipFree(v_out); (void) hipFree(temp);
-  if (rc) return rc;
   RJ_HIP(h, e);
   b.built = true;
   return RJ_OK;
@@ -398,27 +418,11 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
     }
     if (!incoherent) return RJ_OK;
   }
-  if (n > h->ord_cap) {
-    (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout);
-    h->ord_kin = h->ord_kout = nullptr; h->ord_vin = h->ord_vout = nullptr; h->ord_cap = 0;
-    if (int r = dev_alloc(h, &h->ord_kin, n)) return r;
-    if (int r = dev_alloc(h, &h->ord_kout, n)) return r;
-    if (int r = dev_alloc(h, &h->ord_vin, n)) return r;
-    if (int r = dev_alloc(h, &h->ord_vout, n)) return r;
-    h->ord_cap = n;
-  }
-  size_t need = 0;
-  RJ_HIP(h, sort_pairs_u64_u32(h->stream, nullptr, need, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
-  if (need > h->ord_temp_bytes) {
-    (void) hipFree(h->ord_temp);
-    h->ord_temp = nullptr; h->ord_temp_bytes = 0;
-    RJ_HIP(h, hipMalloc(&h->ord_temp, need));
-    h->ord_temp_bytes = need;
-  }
+  if (int r = ensure_sort_scratch(h, n)) return r;
   tic(h, RJ_T_ORDER);
   RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin));
   size_t tb = h->ord_temp_bytes;
-  RJ_HIP(h, sort_pairs_u64_u32(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
+  RJ_HIP(h, sort_pairs_u64_u32(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n, 0, 64 - kMortonDropBits));
   toc(h, RJ_T_ORDER);
   *order_out = h->ord_vout;
   h->last_ordered = true;

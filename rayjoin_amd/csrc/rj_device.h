@@ -29,6 +29,12 @@ constexpr int kOccShift = 19;                  // 31-bit quantised coordinate ->
 constexpr int kOccDim = 1 << (31 - kOccShift);  // 4096 x 4096 cells = 2 MiB of bits
 constexpr int kOccRowWords = kOccDim / 32;
 constexpr int kOccMaxCellsPerSeg = 4096;  // larger boxes are not rasterised; word [kOccDim*kOccRowWords] flags that
+// Morton keys only need their top bits: below 2^-20 of the map extent per axis the order inside a
+// cell does not change tree quality (ties keep eid order = chain order, the sort is stable), and
+// every 8 bits dropped is one radix pass less.  The keys are stored already shifted and sorted over
+// bits [0, 64 - kMortonDropBits): rocPRIM 4.2's merge-sort path (10^4..10^6 items) returns a
+// non-permutation for begin_bit > 0 (tools/sort_probe.hip), begin_bit = 0 is fine at every size.
+constexpr unsigned kMortonDropBits = 24;
 constexpr int32_t kEmptyMin = 0x7FFFFFFF;
 constexpr int32_t kEmptyMax = -1;
 
@@ -90,6 +96,16 @@ __device__ __forceinline__ int32_t wave_max(int32_t v) {
   RJ_DPP_STEP(rj_max32, v, 0x128, 0xf);
   RJ_DPP_STEP(rj_max32, v, 0x142, 0xa);
   RJ_DPP_STEP(rj_max32, v, 0x143, 0xc);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t rj_or32(uint32_t a, uint32_t b) { return a | b; }
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+  RJ_DPP_STEP(rj_or32, v, 0xb1, 0xf);
+  RJ_DPP_STEP(rj_or32, v, 0x4e, 0xf);
+  RJ_DPP_STEP(rj_or32, v, 0x124, 0xf);
+  RJ_DPP_STEP(rj_or32, v, 0x128, 0xf);
+  RJ_DPP_STEP(rj_or32, v, 0x142, 0xa);
+  RJ_DPP_STEP(rj_or32, v, 0x143, 0xc);
   return __builtin_amdgcn_readlane(v, 63);
 }
 #undef RJ_DPP_STEP

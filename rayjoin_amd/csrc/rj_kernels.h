@@ -46,7 +46,8 @@ hipError_t launch_build_segs(hipStream_t st, const int64_t* pts, const uint32_t*
                              uint32_t nc, uint64_t ne, Seg* seg, uint32_t* edge_chain);
 hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, uint64_t* keys, uint32_t* vals);
 hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
-                              uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n);
+                              uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, unsigned begin_bit = 0,
+                              unsigned end_bit = 64);
 hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
                          uint64_t* kout, uint64_t n);
 hipError_t launch_xsect_keys(hipStream_t st, const XsectRec* rec, uint64_t n, int im, uint64_t* keys, uint32_t* vals);
@@ -54,11 +55,10 @@ hipError_t launch_xsect_gather(hipStream_t st, const XsectRec* in, const uint32_
 hipError_t launch_xsect_order_runs(hipStream_t st, XsectRec* rec, uint64_t n, int im, const Seg* seg_im, int64_t* midpts);
 hipError_t launch_xsect_set_mid(hipStream_t st, XsectRec* rec, uint64_t n, int im, const int32_t* face);
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
-hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
-                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t n0p, Seg* sseg,
-                                uint32_t* seid, int32_t* sface, QBox* box0);
-hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0, int32_t* pmx1, uint64_t nblocks);
-hipError_t launch_mark_occupancy(hipStream_t st, const QBox* box0, uint64_t n0, uint32_t* occ);
+hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
+                               const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t nblocks,
+                               uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
+                               int32_t* pmx1, QBox* lvl1, uint32_t* occ);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks);

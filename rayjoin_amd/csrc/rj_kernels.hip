@@ -58,74 +58,59 @@ __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uin
     uint64_t mx = (uint64_t) (((s.x1 + s.x2) >> 1) + kCoordOffset);  // 47 bits
     uint64_t my = (uint64_t) (((s.y1 + s.y2) >> 1) + kCoordOffset);
     uint32_t ux = (uint32_t) (mx >> 15), uy = (uint32_t) (my >> 15);
-    keys[e] = (spread32(uy) << 1) | spread32(ux);
+    keys[e] = ((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits;
     vals[e] = (uint32_t) e;
   }
 }
-
-__global__ __launch_bounds__(256) void k_gather_sorted(const Seg* __restrict__ seg,
-                                                       const uint32_t* __restrict__ order,
-                                                       const uint32_t* __restrict__ edge_chain,
-                                                       const uint32_t* __restrict__ left,
-                                                       const uint32_t* __restrict__ right,
-                                                       uint64_t ne, uint64_t n0p,
-                                                       Seg* __restrict__ sseg,
-                                                       uint32_t* __restrict__ seid,
-                                                       int32_t* __restrict__ sface,
-                                                       QBox* __restrict__ box0) {
-  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n0p;
-       i += (uint64_t) gridDim.x * blockDim.x) {
-    Seg s = {0, 0, 0, 0};
-    QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
-    uint32_t id = 0xFFFFFFFFu;
-    int32_t face = 0;
-    if (i < ne) {
-      id = order[i];
-      s = seg[id];
-      const uint32_t c = edge_chain[id];
-      face = (int32_t) (s.x1 < s.x2 ? right[c] : left[c]);  // get_face_id, map.h:79-87
-      b.x0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
-      b.x1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
-      b.y0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
-      b.y1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
-    }
-    sseg[i] = s;
-    seid[i] = id;
-    sface[i] = face;
-    box0[i] = b;
-  }
-}
-
 
 // Occupancy bitmap of the indexed map: every cell a segment's quantised box touches is set.
 // Two boxes that overlap share a point, hence a cell, so "no set bit under the query box" proves
 // the query can have no candidate: the LSI kernel drops such lanes before the traversal (most of
 // a sparse join) and, when a whole group is clear, skips the tree with ONE gather.
-__global__ __launch_bounds__(256) void k_mark_occupancy(const QBox* __restrict__ box0, uint64_t n0,
-                                                        uint32_t* __restrict__ occ) {
-  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n0;
-       i += (uint64_t) gridDim.x * blockDim.x) {
-    const QBox b = box0[i];
-    if (b.x1 < b.x0) continue;  // padding
-    const int cx0 = b.x0 >> kOccShift, cx1 = b.x1 >> kOccShift;
-    const int cy0 = b.y0 >> kOccShift, cy1 = b.y1 >> kOccShift;
-    if ((int64_t) (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > kOccMaxCellsPerSeg) {
-      // a segment whose box covers a large part of the map: rasterising its box would cost up to
-      // 512 k atomics per segment; raise the "bitmap not exhaustive" word instead (the LSI kernel
-      // then skips the pre-filter -- a performance hint, never a correctness input)
-      atomicOr(&occ[(size_t) kOccDim * kOccRowWords], 1u);
-      continue;
+__device__ __forceinline__ void occ_or(uint32_t* word, uint32_t mask) {
+  // neighbouring segments set the same bits: look (past the L1) before paying an atomic
+  if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) != mask) atomicOr(word, mask);
+}
+// one wave marks its 64 boxes (any order inside the wave; `valid` = not a padding slot)
+__device__ __forceinline__ void mark_occupancy_wave(const QBox& b, bool valid, uint32_t* __restrict__ occ, int lane) {
+  const int cx0 = b.x0 >> kOccShift, cx1 = b.x1 >> kOccShift;
+  const int cy0 = b.y0 >> kOccShift, cy1 = b.y1 >> kOccShift;
+  // Common case: the box lies inside one 32-cell word horizontally and spans at most two rows.
+  // The 64 segments of a leaf block are Morton neighbours, so most of the wave targets the same
+  // few words: OR the masks per distinct word across the wave (DPP), then the leader lanes fire
+  // one atomicOr each -- no return value, so nothing waits on the L2 round trip.
+  const bool simple = valid && cy1 - cy0 <= 1 && (cx0 >> 5) == (cx1 >> 5);
+  const int lo = cx0 & 31, hi = cx1 & 31;
+  const uint32_t mask = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+  for (int row = 0; row < 2; row++) {
+    const bool act = simple && (row == 0 || cy1 > cy0);
+    const uint32_t widx = (uint32_t) (cy0 + row) * kOccRowWords + (uint32_t) (cx0 >> 5);
+    uint64_t todo = __ballot(act);
+    uint32_t lead_mask = 0;
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t w = (uint32_t) bcast((int32_t) widx, leader);
+      const bool same = act && widx == w;
+      const uint32_t m = wave_or(same ? mask : 0u);
+      if (lane == leader) lead_mask = m;
+      todo &= ~__ballot(same);
     }
-    for (int cy = cy0; cy <= cy1; cy++)
-      for (int w = cx0 >> 5; w <= (cx1 >> 5); w++) {
-        const int lo = w == (cx0 >> 5) ? (cx0 & 31) : 0;
-        const int hi = w == (cx1 >> 5) ? (cx1 & 31) : 31;
-        const uint32_t mask = (hi == 31 ? 0xFFFFFFFFu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-        uint32_t* word = &occ[(size_t) cy * kOccRowWords + w];
-        // neighbouring segments set the same bits: look (past the L1) before paying an atomic
-        if ((__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mask) != mask) atomicOr(word, mask);
-      }
+    if (lead_mask) atomicOr(&occ[widx], lead_mask);
   }
+  if (!valid || simple) return;
+  if ((int64_t) (cx1 - cx0 + 1) * (cy1 - cy0 + 1) > kOccMaxCellsPerSeg) {
+    // a segment whose box covers a large part of the map: rasterising its box would cost up to
+    // 512 k atomics per segment; raise the "bitmap not exhaustive" word instead (the LSI kernel
+    // then skips the pre-filter -- a performance hint, never a correctness input)
+    atomicOr(&occ[(size_t) kOccDim * kOccRowWords], 1u);
+    return;
+  }
+  for (int cy = cy0; cy <= cy1; cy++)
+    for (int w = cx0 >> 5; w <= (cx1 >> 5); w++) {
+      const int l = w == (cx0 >> 5) ? (cx0 & 31) : 0;
+      const int h = w == (cx1 >> 5) ? (cx1 & 31) : 31;
+      occ_or(&occ[(size_t) cy * kOccRowWords + w], (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u));
+    }
 }
 
 __device__ __forceinline__ bool occ_any(const uint32_t* __restrict__ occ, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
@@ -139,25 +124,50 @@ __device__ __forceinline__ bool occ_any(const uint32_t* __restrict__ occ, int32_
   return ((a | b | c | d) & 1u) != 0;
 }
 
+// Leaf construction, one wave per 64-segment block, one pass over the data: gather the block's
+// segments through the sorted order, derive face id (get_face_id, map.h:79-87) and quantised box,
+// mark the occupancy bitmap, order the block, write it once, and emit the block's level-1 box.
 // Inside a leaf block the order of the 64 segments is free (upper levels only see the union),
 // so each block is sorted by box x0 and gets pmx1[j] = max(x1[0..j]).  A query lane then finds its
-// candidates with a 6-step cross-lane binary search (segments with x0 <= key form a prefix) and
-// a backward scan that stops as soon as pmx1 drops below the query's x -- one or two steps for
+// candidates with a cross-lane binary search (segments with x0 <= key form a prefix) and a
+// backward scan that stops as soon as pmx1 drops below the query's x -- one or two steps for
 // an x-monotone run of a polyline instead of a 64-iteration uniform loop.
-__global__ __launch_bounds__(256) void k_sort_leaf_blocks(Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
-                                                          int32_t* __restrict__ sface, QBox* __restrict__ box0,
-                                                          int32_t* __restrict__ pmx1, uint64_t nblocks) {
+__global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ seg, const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ edge_chain,
+                                                      const uint32_t* __restrict__ left,
+                                                      const uint32_t* __restrict__ right, uint64_t ne,
+                                                      uint64_t nblocks, uint64_t n_parent_alloc,
+                                                      Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
+                                                      int32_t* __restrict__ sface, QBox* __restrict__ box0,
+                                                      int32_t* __restrict__ pmx1, QBox* __restrict__ lvl1,
+                                                      uint32_t* __restrict__ occ) {
   __shared__ int32_t sx1[4][64];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
-  uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+  const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
-  for (uint64_t blk = wave; blk < nblocks; blk += nwaves) {
+  for (uint64_t blk = wave; blk < n_parent_alloc; blk += nwaves) {
+    if (blk >= nblocks) {  // padding of level 1
+      if (lane == 0) lvl1[blk] = QBox{kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
+      continue;
+    }
     const uint64_t i = blk * 64 + lane;
-    const Seg s = sseg[i];
-    const uint32_t id = seid[i];
-    const int32_t fc = sface[i];
-    const QBox b = box0[i];
+    Seg s = {0, 0, 0, 0};
+    QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
+    uint32_t id = 0xFFFFFFFFu;
+    int32_t fc = 0;
+    const bool valid = i < ne;
+    if (valid) {
+      id = __builtin_nontemporal_load(&order[i]);
+      s = seg[id];
+      const uint32_t c = edge_chain[id];
+      fc = (int32_t) (s.x1 < s.x2 ? right[c] : left[c]);
+      b.x0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
+      b.x1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
+      b.y0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
+      b.y1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+    }
+    mark_occupancy_wave(b, valid, occ, lane);
     int rank = 0;
     for (int k = 0; k < 64; k++) {
       const int32_t xk = bcast(b.x0, k);
@@ -178,6 +188,8 @@ __global__ __launch_bounds__(256) void k_sort_leaf_blocks(Seg* __restrict__ sseg
     }
     pmx1[blk * 64 + lane] = m;
     wave_lds_fence();
+    const int32_t ux0 = wave_min(b.x0), uy0 = wave_min(b.y0), ux1 = wave_max(b.x1), uy1 = wave_max(b.y1);
+    if (lane == 0) lvl1[blk] = QBox{ux0, uy0, ux1, uy1};
   }
 }
 
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256) void k_query_keys(const int64_t* __restrict__ 
       mx = (s.x1 + s.x2) >> 1; my = (s.y1 + s.y2) >> 1;
     }
     const uint32_t ux = (uint32_t) ((uint64_t) (mx + kCoordOffset) >> 15), uy = (uint32_t) ((uint64_t) (my + kCoordOffset) >> 15);
-    keys[i] = (spread32(uy) << 1) | spread32(ux);
+    keys[i] = ((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits;
     vals[i] = (uint32_t) i;  // index relative to `begin`
   }
 }
@@ -900,8 +912,9 @@ hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, uint64_t* 
 }
 
 hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
-                              uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n) {
-  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t) n, 0, 64, st);
+                              uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, unsigned begin_bit,
+                              unsigned end_bit) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t) n, begin_bit, end_bit, st);
 }
 
 hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
@@ -932,21 +945,12 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {
   return hipGetLastError();
 }
 
-hipError_t launch_gather_sorted(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
-                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t n0p, Seg* sseg,
-                                uint32_t* seid, int32_t* sface, QBox* box0) {
-  hipLaunchKernelGGL(k_gather_sorted, dim3(grid_for(n0p, 256, 8192)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, n0p, sseg, seid, sface, box0);
-  return hipGetLastError();
-}
-
-hipError_t launch_sort_leaf_blocks(hipStream_t st, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0, int32_t* pmx1, uint64_t nblocks) {
-  hipLaunchKernelGGL(k_sort_leaf_blocks, dim3(grid_for(nblocks, 4, 8192)), dim3(256), 0, st, sseg, seid, sface, box0, pmx1, nblocks);
-  return hipGetLastError();
-}
-
-hipError_t launch_mark_occupancy(hipStream_t st, const QBox* box0, uint64_t n0, uint32_t* occ) {
-  hipLaunchKernelGGL(k_mark_occupancy, dim3(grid_for(n0, 256, 8192)), dim3(256), 0, st, box0, n0, occ);
+hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
+                               const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t nblocks,
+                               uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
+                               int32_t* pmx1, QBox* lvl1, uint32_t* occ) {
+  hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
+                     left, right, ne, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, lvl1, occ);
   return hipGetLastError();
 }
 

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Index build time (rj_build_lbvh, device timer) per stand-in map, best of --reps (GPU only)."""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rayjoin_amd import _capi, maps, synth  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--maps", default="USCounty,BlockGroup,LakesNA")
+ap.add_argument("--scale", type=float, default=1.0)
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+out = {}
+for name in a.maps.split(","):
+    g = synth.standin(name, a.scale)
+    ctx = maps.Context([g, None]).load()
+    m = ctx.maps[0]
+    h = _capi.Handle(0)
+    h.upload_map(0, m.pts, m.row_index, m.left, m.right)
+    ms = []
+    for _ in range(a.reps):
+        h.build_lbvh(0)
+        ms.append(h.last_ms(_capi.RJ_T_BUILD))
+    out[name] = {"segments": int(m.n_edges), "first_build_ms": round(ms[0], 3), "build_ms": round(min(ms), 3),
+                 "Msegs_per_s": round(m.n_edges / min(ms) / 1e3, 1)}
+    h.close()
+print(json.dumps(out))
