@@ -67,7 +67,7 @@ struct rj_handle_s {
   struct CohCache { bool valid = false; uint64_t begin = 0, n = 0; bool incoherent = false; } coh[2][2];
   // grow-only scratch of the query-ordering pass
   uint64_t ord_cap = 0;
-  uint64_t *ord_kin = nullptr, *ord_kout = nullptr;
+  MortonKey *ord_kin = nullptr, *ord_kout = nullptr;
   uint32_t *ord_vin = nullptr, *ord_vout = nullptr;
   void* ord_temp = nullptr;
   size_t ord_temp_bytes = 0;
@@ -315,7 +315,7 @@ static int ensure_sort_scratch(rj_handle h, uint64_t n) {
     h->ord_cap = n;
   }
   size_t need = 0;
-  RJ_HIP(h, sort_pairs_u64_u32(h->stream, nullptr, need, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n, 0, 64 - kMortonDropBits));
+  RJ_HIP(h, sort_morton_pairs(h->stream, nullptr, need, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
   if (need > h->ord_temp_bytes) {
     (void) hipFree(h->ord_temp);
     h->ord_temp = nullptr; h->ord_temp_bytes = 0;
@@ -366,14 +366,14 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   // 1. Morton keys  2. radix sort (key, eid)  3. leaves + occupancy + level 1 in one pass  4. upper levels
   if (m.ne)
     if (int r = ensure_sort_scratch(h, m.ne)) return r;
-  uint64_t *k_in = h->ord_kin, *k_out = h->ord_kout;
+  MortonKey *k_in = h->ord_kin, *k_out = h->ord_kout;
   uint32_t *v_in = h->ord_vin, *v_out = h->ord_vout;
   hipError_t e = hipSuccess;
   do {
     if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
     if (m.ne) {
       size_t tb = h->ord_temp_bytes;
-      if ((e = sort_pairs_u64_u32(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, m.ne, 0, 64 - kMortonDropBits)) != hipSuccess) break;
+      if ((e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
     }
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p / 64, b.alloc[1],
@@ -422,7 +422,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
   tic(h, RJ_T_ORDER);
   RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin));
   size_t tb = h->ord_temp_bytes;
-  RJ_HIP(h, sort_pairs_u64_u32(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n, 0, 64 - kMortonDropBits));
+  RJ_HIP(h, sort_morton_pairs(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
   toc(h, RJ_T_ORDER);
   *order_out = h->ord_vout;
   h->last_ordered = true;

@@ -29,12 +29,14 @@ constexpr int kOccShift = 19;                  // 31-bit quantised coordinate ->
 constexpr int kOccDim = 1 << (31 - kOccShift);  // 4096 x 4096 cells = 2 MiB of bits
 constexpr int kOccRowWords = kOccDim / 32;
 constexpr int kOccMaxCellsPerSeg = 4096;  // larger boxes are not rasterised; word [kOccDim*kOccRowWords] flags that
-// Morton keys only need their top bits: below 2^-20 of the map extent per axis the order inside a
-// cell does not change tree quality (ties keep eid order = chain order, the sort is stable), and
-// every 8 bits dropped is one radix pass less.  The keys are stored already shifted and sorted over
-// bits [0, 64 - kMortonDropBits): rocPRIM 4.2's merge-sort path (10^4..10^6 items) returns a
-// non-permutation for begin_bit > 0 (tools/sort_probe.hip), begin_bit = 0 is fine at every size.
-constexpr unsigned kMortonDropBits = 24;
+// Morton keys keep only their top 32 bits (16 per axis over the scaled +-2^46 domain; the reference's
+// codes have 10 per axis, deps/lbvh/lbvh/morton_code.cuh:23-35): finer bits do not change tree
+// quality -- ties keep eid order = chain order, the sort is stable -- and a 32-bit key sorts in 4
+// radix passes instead of 8.  The keys are stored already shifted and sorted from bit 0: rocPRIM
+// 4.2's merge-sort path (10^4..10^6 items) returns a non-permutation for begin_bit > 0
+// (tools/sort_probe.hip), begin_bit = 0 is fine at every size.
+constexpr unsigned kMortonDropBits = 32;
+using MortonKey = uint32_t;  // 64 - kMortonDropBits bits
 constexpr int32_t kEmptyMin = 0x7FFFFFFF;
 constexpr int32_t kEmptyMax = -1;
 

@@ -44,7 +44,9 @@ struct PipArgs {
 
 hipError_t launch_build_segs(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin,
                              uint32_t nc, uint64_t ne, Seg* seg, uint32_t* edge_chain);
-hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, uint64_t* keys, uint32_t* vals);
+hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, MortonKey* keys, uint32_t* vals);
+hipError_t sort_morton_pairs(hipStream_t st, void* temp, size_t& temp_bytes, const MortonKey* kin, MortonKey* kout,
+                             const uint32_t* vin, uint32_t* vout, uint64_t n);
 hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
                               uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, unsigned begin_bit = 0,
                               unsigned end_bit = 64);
@@ -65,7 +67,7 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_bloc
 hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                                uint64_t n, unsigned long long* out2);
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
-                             uint64_t n, uint64_t* keys, uint32_t* vals);
+                             uint64_t n, MortonKey* keys, uint32_t* vals);
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
                              uint64_t n, XsectRec* out);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);

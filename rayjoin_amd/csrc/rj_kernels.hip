@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t spread32(uint32_t v) {  // insert a 0 bit be
 
 // 64-bit Morton key straight from the int64 midpoint (no float, 32 bits per axis, y is the MSB)
 __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uint64_t ne,
-                                                uint64_t* __restrict__ keys,
+                                                MortonKey* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
   for (uint64_t e = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; e < ne;
        e += (uint64_t) gridDim.x * blockDim.x) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uin
     uint64_t mx = (uint64_t) (((s.x1 + s.x2) >> 1) + kCoordOffset);  // 47 bits
     uint64_t my = (uint64_t) (((s.y1 + s.y2) >> 1) + kCoordOffset);
     uint32_t ux = (uint32_t) (mx >> 15), uy = (uint32_t) (my >> 15);
-    keys[e] = ((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits;
+    keys[e] = (MortonKey) (((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits);
     vals[e] = (uint32_t) e;
   }
 }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_group_extent(const int64_t* __restrict_
 
 template <bool POINTS>
 __global__ __launch_bounds__(256) void k_query_keys(const int64_t* __restrict__ pts, const Seg* __restrict__ segs,
-                                                    uint64_t begin, uint64_t n, uint64_t* __restrict__ keys,
+                                                    uint64_t begin, uint64_t n, MortonKey* __restrict__ keys,
                                                     uint32_t* __restrict__ vals) {
   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
     int64_t mx, my;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_query_keys(const int64_t* __restrict__ 
       mx = (s.x1 + s.x2) >> 1; my = (s.y1 + s.y2) >> 1;
     }
     const uint32_t ux = (uint32_t) ((uint64_t) (mx + kCoordOffset) >> 15), uy = (uint32_t) ((uint64_t) (my + kCoordOffset) >> 15);
-    keys[i] = ((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits;
+    keys[i] = (MortonKey) (((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits);
     vals[i] = (uint32_t) i;  // index relative to `begin`
   }
 }
@@ -905,7 +905,7 @@ hipError_t launch_build_segs(hipStream_t st, const int64_t* pts, const uint32_t*
   return hipGetLastError();
 }
 
-hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, uint64_t* keys, uint32_t* vals) {
+hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, MortonKey* keys, uint32_t* vals) {
   if (ne == 0) return hipSuccess;
   hipLaunchKernelGGL(k_morton, dim3(grid_for(ne, 256, 8192)), dim3(256), 0, st, seg, ne, keys, vals);
   return hipGetLastError();
@@ -915,6 +915,11 @@ hipError_t sort_pairs_u64_u32(hipStream_t st, void* temp, size_t& temp_bytes, co
                               uint64_t* kout, const uint32_t* vin, uint32_t* vout, uint64_t n, unsigned begin_bit,
                               unsigned end_bit) {
   return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t) n, begin_bit, end_bit, st);
+}
+
+hipError_t sort_morton_pairs(hipStream_t st, void* temp, size_t& temp_bytes, const MortonKey* kin, MortonKey* kout,
+                             const uint32_t* vin, uint32_t* vout, uint64_t n) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t) n, 0, 64 - kMortonDropBits, st);
 }
 
 hipError_t sort_keys_u64(hipStream_t st, void* temp, size_t& temp_bytes, const uint64_t* kin,
@@ -1009,7 +1014,7 @@ hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, 
 }
 
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
-                             uint64_t n, uint64_t* keys, uint32_t* vals) {
+                             uint64_t n, MortonKey* keys, uint32_t* vals) {
   if (n == 0) return hipSuccess;
   if (points)
     hipLaunchKernelGGL(k_query_keys<true>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals);
