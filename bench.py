@@ -143,24 +143,32 @@ def main():
     sh = rjd.shard_of(query, world, rank)
     (e0, e1), (p0, p1) = sh["eids"], sh["points"]
     cap = int(args.xsect_factor * (n_r + n_s))  # run_query.cu:226-228
-    pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
     closest = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
     faces = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
     if world > 1:
+        # count + pairs leave in one all-gather on a second stream, overlapped with the PIP kernel
+        ex = rjd.PairExchange(cap, dev, slot=max(4096, int(0.02 * cap)))
+        pairs = ex.pairs
         max_pts = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
-        scratch = torch.empty(world * cap * 2, dtype=torch.int32, device=dev)
+    else:
+        pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
 
     lsi_ms, pip_ms = [], []
     state = {}
 
     def step(record):
-        n = h.lsi_query(0, 1, e0, e1, cap, pairs)
+        # both kernels are enqueued back to back; the step's single host sync is the count read-back
+        h.lsi_query_async(0, 1, e0, e1, cap, pairs)
+        if world > 1:
+            ex.begin(h)
+        h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+        if world > 1:  # RCCL all-gather-v of the intersection queues (rank order, zero-copy views)
+            state["pairs_all"], state["cnt_all"] = ex.finish()
+            n = state["cnt_all"][rank]
+        else:
+            n = h.lsi_query_finish(cap)
         if record:
             lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
-        if world > 1:  # RCCL all-gather-v of the intersection queues
-            state["pairs_all"], state["cnt_all"] = rjd.allgather_pairs(pairs, n, scratch)
-        h.pip_query(0, 1, None, p0, p1 - p0, closest, faces)
-        if record:
             pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
         if world > 1 and args.gather_pip:  # optional: all-gather of the PIP result queues
             state["ids_all"] = rjd.allgather_point_results(closest, p1 - p0, max_pts)

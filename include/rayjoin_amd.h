@@ -99,6 +99,12 @@ int rj_lsi_query(rj_handle h, int base_map_id, int query_map_id, uint64_t query_
 int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t query_eid_begin,
                        uint64_t query_eid_end, uint64_t capacity, uint32_t* pairs_dev);
 int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found);
+/* Device-side Queue::size (src/util/queue.h:125-129 reads the tail counter back to the host):
+ * enqueue, on the handle's stream, a copy of the last rj_lsi_query_async's result count (the TRUE
+ * count, which exceeds the capacity after an overflow) into n_found_dev[0] (device memory, 8 bytes).
+ * A multi-GPU caller puts it at the head of its exchange buffer and ships count + pairs in one
+ * collective with no host round trip between the LSI kernel and the exchange. */
+int rj_lsi_count_to(rj_handle h, uint64_t* n_found_dev);
 
 /* replaces: the intersection-point half of dev::intersect_test + the narrowing store into
  * Intersection<int64_t> (src/algo/lsi.h:107-143, src/app/lsi_lbvh.h:71-78).

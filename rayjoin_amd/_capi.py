@@ -36,6 +36,7 @@ SYMBOLS = {
     "rj_lsi_query": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp, C.POINTER(_u64)]),
     "rj_lsi_query_async": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp]),
     "rj_lsi_query_finish": (_int, [_vp, _u64, C.POINTER(_u64)]),
+    "rj_lsi_count_to": (_int, [_vp, _vp]),
     "rj_lsi_points": (_int, [_vp, _vp, _u64, _vp]),
     "rj_sort_pairs": (_int, [_vp, _vp, _u64]),
     "rj_comm_unique_id": (_int, [_vp]),
@@ -223,6 +224,10 @@ class Handle:
             raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
         self._check(rc)
         return n.value
+
+    def lsi_count_to(self, n_found_dev):
+        """device-side Queue::size: copy the last async LSI's count (u64) to device memory, on the stream"""
+        self._check(self.L.rj_lsi_count_to(self.h, _ptr(n_found_dev)))
 
     def lsi_points(self, pairs_dev, n, out_dev):
         self._check(self.L.rj_lsi_points(self.h, _ptr(pairs_dev), n, _ptr(out_dev)))

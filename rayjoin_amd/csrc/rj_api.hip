@@ -481,6 +481,14 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   return RJ_OK;
 }
 
+int rj_lsi_count_to(rj_handle h, uint64_t* n_found_dev) {
+  RJ_CHECK_H(h);
+  if (!n_found_dev) return fail(h, RJ_E_INVALID, "rj_lsi_count_to: null destination");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipMemcpyAsync(n_found_dev, h->d_counter, 8, hipMemcpyDeviceToDevice, h->stream));
+  return RJ_OK;
+}
+
 int rj_lsi_query(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
                  uint64_t capacity, uint32_t* pairs_dev, uint64_t* n_found) {
   RJ_CHECK_H(h);

@@ -77,3 +77,78 @@ def allgather_point_results(ids, n, max_n):
     recv = flat.view(world, max_n)
     counts = allgather_counts(n, ids.device).tolist()
     return torch.cat([recv[r, :counts[r]] for r in range(world)], dim=0)
+
+
+class PairExchange:
+    """One-collective, overlapped all-gather-v of the LSI result queues.
+
+    The sender's buffer is `[count (u64) | pairs ...]` (`send`, int32): the LSI kernel appends
+    pairs behind the 8-byte head, `rj_lsi_count_to` drops the device-side count into the head on
+    the same stream, and ONE all-gather of the first `2 + 2*slot` ints of every rank ships count and
+    pairs together -- no host round trip between the LSI kernel and the exchange.  The collective
+    runs on its own stream behind an event, so the PIP kernel that follows the LSI kernel on the
+    compute stream overlaps it.  `slot` (pairs shipped per rank) adapts to twice the largest
+    count seen; a step whose count exceeds the slot is re-gathered with a larger slot, so the
+    result is always complete.
+
+    usage per step:  h.lsi_query_async(..., capacity, ex.pairs);  ex.begin(h);
+                     <enqueue more compute>;  views, counts = ex.finish()
+    """
+
+    def __init__(self, capacity, device, slot=4096):
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.capacity = int(capacity)
+        self.device = device
+        self.send = torch.zeros(2 + 2 * self.capacity, dtype=torch.int32, device=device)
+        self.pairs = self.send[2:].view(self.capacity, 2)  # hand this to the LSI query
+        self.slot = min(int(slot), self.capacity)
+        self.recv = None
+        self.comm_stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        self._ready = None
+
+    def _recv_for(self, slot):
+        need = self.world * (2 + 2 * slot)
+        if self.recv is None or self.recv.numel() < need:
+            self.recv = torch.empty(need, dtype=torch.int32, device=self.device)
+        return self.recv[:need]
+
+    def _gather(self, slot):
+        out = self._recv_for(slot)
+        _all_gather_flat(out, self.send[:2 + 2 * slot])
+        return out.view(self.world, 2 + 2 * slot)
+
+    def begin(self, handle):
+        """after the async LSI launch: stamp the count, then start the exchange behind an event"""
+        handle.lsi_count_to(self.send)
+        if self.comm_stream is None or _needs_host_staging(self.send):
+            self._ready = None  # synchronous path (gloo): everything happens in finish()
+            return
+        ev = torch.cuda.Event()
+        ev.record()  # on the compute stream: count + pairs are complete here
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            self._ready = self._gather(self.slot)
+
+    def finish(self):
+        """-> ([pairs view of rank 0, rank 1, ...], counts list); syncs once"""
+        if self._ready is None:
+            got = self._gather(self.slot)
+        else:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+            got = self._ready
+        head = got[:, :2].cpu()  # the step's one host sync
+        counts = [int(head[r, 0]) & 0xFFFFFFFF | (int(head[r, 1]) & 0xFFFFFFFF) << 32 for r in range(self.world)]
+        if counts[self.rank] > self.capacity:
+            raise OverflowError("intersection queue overflow: %d found, capacity %d" % (counts[self.rank], self.capacity))
+        if max(counts) > self.capacity:
+            raise OverflowError("intersection queue overflow on another rank")
+        if max(counts) > self.slot:  # rare: grow the slot and gather this step again
+            self.slot = min(self.capacity, 2 * max(counts))
+            got = self._gather(self.slot)
+            if got.is_cuda:
+                torch.cuda.current_stream().synchronize()
+        elif 4 * max(counts) < self.slot and self.slot > 4096:
+            self.slot = max(4096, 2 * max(counts))  # shrink for the next step
+        self._ready = None
+        return [got[r, 2:2 + 2 * counts[r]].view(-1, 2) for r in range(self.world)], counts

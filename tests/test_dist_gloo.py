@@ -46,6 +46,20 @@ def _worker(rank, world, port, out_dir):
     got = O.sort_pairs(gathered.numpy().astype(np.uint32))
     assert int(counts.sum()) == len(whole)
     assert np.array_equal(got, whole), "rank %d: gathered LSI pairs differ from the whole-map result" % rank
+    # the one-collective exchange bench.py uses on RCCL (count rides at the head of the buffer);
+    # slot 16 is far too small on purpose: the first finish() must grow it and re-gather
+    class _FakeHandle:  # stands in for rj_lsi_count_to: the device-side count copy
+        def lsi_count_to(self, send):
+            send[0] = len(mine)
+            send[1] = 0
+    ex = rjd.PairExchange(cap, torch.device("cpu"), slot=16)
+    for rep in range(2):
+        ex.pairs[:len(mine)] = torch.from_numpy(mine.astype(np.int32))
+        ex.begin(_FakeHandle())
+        views, cl = ex.finish()
+        assert cl == [int(c) for c in counts] and ex.slot >= max(cl)
+        got2 = O.sort_pairs(torch.cat(views).numpy().astype(np.uint32))
+        assert np.array_equal(got2, whole), "rank %d rep %d: PairExchange result differs" % (rank, rep)
     # PIP: contiguous point shards concatenate back in point order
     p0, p1 = sh["points"]
     want = O.pip_brute(m0, 1, query.pts)
