@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--cpu-scale", type=float, default=1.0)
     ap.add_argument("--check", action="store_true", help="size-independent result checks after timing")
     ap.add_argument("--gather-pip", action="store_true", help="N>1: also all-gather the PIP result queues every step")
+    ap.add_argument("--emulate-shard", type=int, default=0, metavar="N",
+                    help="diagnostic, 1 GPU: time rank 0's shard of an N-way run (no exchange); the line is marked as such")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0, collectives over gloo")
     return ap.parse_args()
@@ -140,7 +142,7 @@ def main():
 
     # ---- shard the query map by chain range -------------------------------------
     from rayjoin_amd import dist as rjd
-    sh = rjd.shard_of(query, world, rank)
+    sh = rjd.shard_of(query, args.emulate_shard, 0) if (args.emulate_shard and world == 1) else rjd.shard_of(query, world, rank)
     (e0, e1), (p0, p1) = sh["eids"], sh["points"]
     cap = int(args.xsect_factor * (n_r + n_s))  # run_query.cu:226-228
     closest = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
@@ -233,7 +235,8 @@ def main():
                                    "-mode=lbvh (software LBVH)" % (args.base, n_r, args.query, n_s, n_p),
                        "sharding": ("query map by chain range x%d, base+LBVH replicated, RCCL all-gather-v of LSI pairs%s"
                                     % (world, " and PIP eids" if args.gather_pip else "; PIP results stay with their shard"))
-                                   if world > 1 else "single GPU",
+                                   if world > 1 else ("single GPU" if not args.emulate_shard else
+                                                      "DIAGNOSTIC: rank 0's shard of a %d-way run on one GPU, value is NOT a job throughput" % args.emulate_shard),
                        "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
