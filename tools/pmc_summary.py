@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc counter_collection CSVs (one directory per counter pass) into
+profiles/<tag>_pmc_summary.csv and profiles/traffic.json.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and on gfx950
+FETCH_SIZE reports half of the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section;
+calibrated on k_build_segs in profiles/README.md).
+
+usage: pmc_summary.py <tag> <fetch_dir> <write_dir>
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    if "onesweep" in name or "radix" in name:
+        return "rocprim_radix_sort"
+    m = re.search(r"rj::(k_[a-z_0-9]+)", name)
+    if m:
+        return m.group(1)
+    return name.split("(")[0][:40]
+
+
+def collect(d):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            acc[r["Counter_Name"]][short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return acc
+
+
+def main():
+    tag, fetch_dir, write_dir = sys.argv[1:4]
+    acc = collect(fetch_dir)
+    for k, v in collect(write_dir).items():
+        acc[k].update(v)
+    rows = []
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for kern, vals in sorted(acc.get(counter, {}).items()):
+            rows.append((counter, kern, len(vals), sum(vals) / len(vals)))
+    out = os.path.join(ROOT, "profiles", "%s_pmc_summary.csv" % tag)
+    with open(out, "w") as f:
+        f.write("counter,kernel,dispatches,avg_value_KB\n")
+        for r in rows:
+            f.write("%s,%s,%d,%.1f\n" % r)
+    avg = {(c, k): v for c, k, _, v in rows}
+    traffic = {}
+    for kern in ("k_lsi", "k_pip"):
+        if ("FETCH_SIZE", kern) in avg and ("WRITE_SIZE", kern) in avg:
+            traffic[kern] = int((2 * avg[("FETCH_SIZE", kern)] + avg[("WRITE_SIZE", kern)]) * 1024)
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"))
+    print(out, traffic)
+
+
+if __name__ == "__main__":
+    main()
