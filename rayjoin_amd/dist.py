@@ -113,8 +113,8 @@ class PairExchange:
             self.recv = torch.empty(need, dtype=torch.int32, device=self.device)
         return self.recv[:need]
 
-    def _gather(self, slot):
-        out = self._recv_for(slot)
+    def _gather(self, slot, out=None):
+        out = self._recv_for(slot) if out is None else out
         _all_gather_flat(out, self.send[:2 + 2 * slot])
         return out.view(self.world, 2 + 2 * slot)
 
@@ -124,11 +124,12 @@ class PairExchange:
         if self.comm_stream is None or _needs_host_staging(self.send):
             self._ready = None  # synchronous path (gloo): everything happens in finish()
             return
+        out = self._recv_for(self.slot)  # (allocated on the compute stream, where it is consumed)
         ev = torch.cuda.Event()
         ev.record()  # on the compute stream: count + pairs are complete here
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
-            self._ready = self._gather(self.slot)
+            self._ready = self._gather(self.slot, out)
 
     def finish(self):
         """-> ([pairs view of rank 0, rank 1, ...], counts list); syncs once"""
