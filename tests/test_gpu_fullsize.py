@@ -99,3 +99,31 @@ def test_four_level_tree_parity(oracle):
     assert np.array_equal(we, closest.to_host(np.uint32))
     assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
     h.close()
+
+
+def test_lakes_parks_pip_full_base(oracle):
+    """BASELINE.json configs[2] (Lakes x Parks, -query=pip) with the base map at FULL size
+    (66.9 M segments, 1.05 M leaf blocks): every 13th vertex of the Parks stand-in (2.1 M points)
+    against the oracle's grid PIP, bit-exact eids and face ids."""
+    import psutil
+    if psutil.virtual_memory().available < 40 << 30:
+        pytest.skip("needs ~30 GB of host memory for the 66.9 M-segment map and the oracle's grid")
+    oracle.lib().rjo_set_num_threads(16)
+    ctx = maps.Context([synth.standin("LakesNA"), synth.standin("ParksNA")]).load()
+    base, query = ctx.maps
+    assert base.n_edges > 66_000_000
+    pts = np.ascontiguousarray(query.pts[::13])
+    h = _capi.Handle(0)
+    h.upload_map(0, base.pts, base.row_index, base.left, base.right)
+    h.build_lbvh(0)
+    d = h.alloc(16 * len(pts)).from_host(pts)
+    closest = h.alloc(4 * len(pts))
+    faces = h.alloc(4 * len(pts))
+    h.pip_query(0, 1, d, 0, len(pts), closest, faces)
+    m0 = oracle.Map(base.pts, base.row_index, base.left, base.right)
+    we = oracle.pip_grid(m0, 0, pts, 4096)
+    eids = closest.to_host(np.uint32)
+    assert (eids != 0xFFFFFFFF).sum() > len(pts) // 2
+    assert np.array_equal(we, eids)
+    assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
+    h.close()
