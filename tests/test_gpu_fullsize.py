@@ -127,3 +127,21 @@ def test_lakes_parks_pip_full_base(oracle):
     assert np.array_equal(we, eids)
     assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
     h.close()
+
+
+def test_uscounty_zipcode_overlay_stages_full_size():
+    """BASELINE.json configs[3] (USCounty x Zipcode overlay) at FULL size: IntersectEdge,
+    LocateVerticesInOtherMap (both maps) and the per-map ComputeOutputPolygons records, bit-exact
+    against the oracle's -mode=grid pipeline (tools/overlay_probe.py --check does the comparison;
+    run as a child process so its 30 M-segment maps are freed before the next test)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlay_probe.py"), "--check"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["bit_exact_vs_oracle"] is True and out["intersections"] > 10000
+    assert out["map0_edges"] > 7_000_000 and out["map1_edges"] > 23_000_000
