@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
     const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
     const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
     const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
-    double best_yy = __builtin_inf(), best_slope = 0.0;
+    double best_yy = __builtin_inf();
     uint32_t best_slot = 0xFFFFFFFFu;  // sorted slot of the best edge so far (eid/face are looked up at the end)
     int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer
     int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
@@ -719,13 +719,15 @@ __global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
         if (r < cnt) {
           const uint32_t slot = L.cand[r][lane];
           const Seg bs = T.sseg[slot];
-          double yy, slope;
-          if (pip_eval(bs, px, py, qm, &yy, &slope)) {
+          double yy;
+          if (pip_eval_y(bs, px, py, qm, &yy)) {
             bool better = yy < best_yy;
-            if (yy == best_yy && best_slot != 0xFFFFFFFFu)  // tie: slope rule, then eid (rare: look the eids up now)
-              better = pip_better(yy, slope, T.seid[slot], best_yy, best_slope, T.seid[best_slot], qm);
+            if (yy == best_yy && best_slot != 0xFFFFFFFFu) {  // tie: slope rule, then eid (rare: slopes and eids are looked up now)
+              const Seg cur = T.sseg[best_slot];
+              better = pip_better(yy, pip_slope(bs), T.seid[slot], best_yy, pip_slope(cur), T.seid[best_slot], qm);
+            }
             if (better) {
-              best_yy = yy; best_slope = slope; best_slot = slot;
+              best_yy = yy; best_slot = slot;
             }
           }
         }

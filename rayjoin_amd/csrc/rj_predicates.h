@@ -164,21 +164,35 @@ RJ_HD void lsi_point(const Seg& s1, const Eqn& e1, const Seg& s2, const Eqn& e2,
 
 // ---- PIP ------------------------------------------------------------------------------
 // One (point, base edge) evaluation, pip.h:36-71.  Returns false when the edge is rejected
-// outright (x range / point above edge); otherwise *yy = xsect_y and *slope = (double)a/b.
-RJ_HD bool pip_eval(const Seg& s, int64_t px, int64_t py, int query_map_id, double* yy,
-                    double* slope) {
-  int64_t x_min = s.x1 < s.x2 ? s.x1 : s.x2;
-  int64_t x_max = s.x1 < s.x2 ? s.x2 : s.x1;
+// outright (x range / point above edge); otherwise *yy = xsect_y.
+// The reference divides double(-a px - c) by double(b) with (a, b, c) normalised to b >= 0.
+// -a px - c = a (x1 - px) + b y1 exactly (c = -x1 a - y1 b; every term < 2^95), so two 128-bit
+// products instead of three; and normalisation negates numerator and denominator together, which
+// IEEE division cannot see -- so the raw (a, b) are used for the quotient, the normalised ones
+// only for the simulation-of-simplicity substitutes.  b == 0 (vertical edge) never gets here: its
+// x range is one point, which the range rule rejects.
+RJ_HD bool pip_eval_y(const Seg& s, int64_t px, int64_t py, int query_map_id, double* yy) {
+  const int64_t x_min = s.x1 < s.x2 ? s.x1 : s.x2;
+  const int64_t x_max = s.x1 < s.x2 ? s.x2 : s.x1;
   if (px < x_min || px > x_max || px == (query_map_id == 0 ? x_min : x_max)) return false;
-  Eqn e = make_eqn(s);
-  double xsect_y = (double) (-e.a * (i128) px - e.c) / (double) e.b;
+  const int64_t a = s.y1 - s.y2, b = s.x2 - s.x1;
+  const i128 num = (i128) a * (s.x1 - px) + (i128) b * s.y1;
+  const double xsect_y = (double) num / (double) b;
   double diff_y = (double) py - xsect_y;
-  if (diff_y == 0) diff_y = (double) (query_map_id == 0 ? -e.a : e.a);
-  if (diff_y == 0) diff_y = (double) (query_map_id == 0 ? -e.b : e.b);
+  if (diff_y == 0) {
+    const int64_t an = b < 0 ? -a : a, bn = b < 0 ? -b : b;
+    diff_y = (double) (query_map_id == 0 ? -an : an);
+    if (diff_y == 0) diff_y = (double) (query_map_id == 0 ? -bn : bn);
+  }
   if (diff_y > 0) return false;
   *yy = xsect_y;
-  *slope = (double) e.a / (double) e.b;
   return true;
+}
+
+// (double) a / (double) b of the normalised edge equation: only needed to break a tie in xsect_y
+RJ_HD double pip_slope(const Seg& s) {
+  const int64_t a = s.y1 - s.y2, b = s.x2 - s.x1;
+  return (double) (b < 0 ? -a : a) / (double) (b < 0 ? -b : b);
 }
 
 // Does candidate (yy, slope, eid) replace best (byy, bslope, beid)?  pip.h:73-95 made a total
