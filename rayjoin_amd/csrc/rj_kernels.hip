@@ -658,7 +658,7 @@ struct PipWaveLds {
 };
 
 template <bool STATS>
-__global__ __launch_bounds__(256, 5) void k_pip(PipArgs A) {
+__global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
   __shared__ PipWaveLds lds[4];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
