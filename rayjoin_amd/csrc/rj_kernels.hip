@@ -352,10 +352,10 @@ __device__ __forceinline__ void lsi_drain(LsiWaveLds& L, int& np, int& nh, int n
     Seg bs = A.bvh.sseg[pr.y];
     uint32_t beid = A.bvh.seid[pr.y];
     if (A.base_is_map0) {
-      hit = lsi_test(bs, make_eqn(bs), qs, make_eqn(qs));
+      hit = lsi_test(bs, qs);
       h.x = beid; h.y = pr.x;
     } else {
-      hit = lsi_test(qs, make_eqn(qs), bs, make_eqn(bs));
+      hit = lsi_test(qs, bs);
       h.x = pr.x; h.y = beid;
     }
   }

@@ -48,32 +48,44 @@ RJ_HD Eqn make_eqn(const Seg& s) {
   return e;
 }
 
-// p.x*e.a + p.y*e.b + e.c  (lsi.h:32-33).  |p| < 2^46, |a|,|b| < 2^47, |c| < 2^94: no overflow.
-RJ_HD i128 subedge(int64_t px, int64_t py, const Eqn& e) {
-  return (i128) px * (int64_t) e.a + (i128) py * (int64_t) e.b + e.c;
+// Sign of p.x*e.a + p.y*e.b + e.c (lsi.h:32-33) for the edge equation of segment e, WITHOUT
+// building the equation: c = -x1 a - y1 b, so the value is a (px - x1) + b (py - y1) exactly
+// (|a|, |b|, the differences < 2^47: each product < 2^94, no overflow), and normalising the
+// equation to b >= 0 (map.h:216-226) only flips its sign when b < 0.  Two 128-bit products and a
+// handful of registers per evaluation instead of three products and a live 128-bit a, b, c.
+RJ_HD int edge_side(const Seg& e, int64_t px, int64_t py) {
+  const int64_t a = e.y1 - e.y2, b = e.x2 - e.x1;
+  const i128 v = (i128) a * (px - e.x1) + (i128) b * (py - e.y1);
+  const int sg = (v > 0) - (v < 0);
+  return b < 0 ? -sg : sg;
 }
+RJ_HD int sign64(int64_t v) { return (v > 0) - (v < 0); }
 
 // intersect_test(e1 = map-0 edge, e2 = map-1 edge); the operand order is part of the semantics
-// (simulation of simplicity, lsi.h:41-87).
-RJ_HD bool lsi_test(const Seg& s1, const Eqn& e1, const Seg& s2, const Eqn& e2) {
-  i128 u1 = subedge(s1.x1, s1.y1, e2);  // e1_p1 against e2
-  i128 u2 = subedge(s1.x2, s1.y2, e2);
-  if (u1 == 0) u1 = -e2.a;
-  if (u1 == 0) u1 = -e2.b;
+// (simulation of simplicity, lsi.h:41-87).  Only signs are ever used (lsi.h:44-87).
+RJ_HD bool lsi_test(const Seg& s1, const Seg& s2) {
+  const int64_t a2 = s2.y1 - s2.y2, b2 = s2.x2 - s2.x1;  // normalised (a, b) of e2: negate if b < 0
+  const int sa2 = b2 < 0 ? -sign64(a2) : sign64(a2), sb2 = b2 != 0;
+  int u1 = edge_side(s2, s1.x1, s1.y1);  // e1_p1 against e2
+  int u2 = edge_side(s2, s1.x2, s1.y2);
+  if (u1 == 0) u1 = -sa2;
+  if (u1 == 0) u1 = -sb2;
   if (u1 == 0) return false;
-  if (u2 == 0) u2 = -e2.a;
-  if (u2 == 0) u2 = -e2.b;
+  if (u2 == 0) u2 = -sa2;
+  if (u2 == 0) u2 = -sb2;
   if (u2 == 0) return false;
-  if ((u1 > 0 && u2 > 0) || (u1 < 0 && u2 < 0)) return false;
-  i128 v1 = subedge(s2.x1, s2.y1, e1);  // e2_p1 against e1
-  i128 v2 = subedge(s2.x2, s2.y2, e1);
-  if (v1 == 0) v1 = e1.a;
-  if (v1 == 0) v1 = e1.b;
+  if (u1 == u2) return false;
+  const int64_t a1 = s1.y1 - s1.y2, b1 = s1.x2 - s1.x1;
+  const int sa1 = b1 < 0 ? -sign64(a1) : sign64(a1), sb1 = b1 != 0;
+  int v1 = edge_side(s1, s2.x1, s2.y1);  // e2_p1 against e1
+  int v2 = edge_side(s1, s2.x2, s2.y2);
+  if (v1 == 0) v1 = sa1;
+  if (v1 == 0) v1 = sb1;
   if (v1 == 0) return false;
-  if (v2 == 0) v2 = e1.a;
-  if (v2 == 0) v2 = e1.b;
+  if (v2 == 0) v2 = sa1;
+  if (v2 == 0) v2 = sb1;
   if (v2 == 0) return false;
-  if ((v1 > 0 && v2 > 0) || (v1 < 0 && v2 < 0)) return false;
+  if (v1 == v2) return false;
   if ((s1.x1 == s2.x1 && s1.y1 == s2.y1 && s1.x2 == s2.x2 && s1.y2 == s2.y2) ||
       (s1.x1 == s2.x2 && s1.y1 == s2.y2 && s1.x2 == s2.x1 && s1.y2 == s2.y1))
     return false;
