@@ -6,7 +6,8 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are i
 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section;
 calibrated on k_build_segs in profiles/README.md).
 
-usage: pmc_summary.py <tag> <fetch_dir> <write_dir>
+usage: pmc_summary.py <tag> <fetch_dir> <write_dir> [<sq_dir> ...]
+(the optional SQ_* passes of tools/profile_run.sh go to profiles/<tag>_sq_counters.csv, k_lsi / k_pip only)
 """
 import collections
 import csv
@@ -38,6 +39,15 @@ def collect(d):
 
 def main():
     tag, fetch_dir, write_dir = sys.argv[1:4]
+    if len(sys.argv) > 4:
+        with open(os.path.join(ROOT, "profiles", "%s_sq_counters.csv" % tag), "w") as f:
+            f.write("counter,kernel,dispatches,avg_value\n")
+            for d in sys.argv[4:]:
+                for counter, per_kernel in sorted(collect(d).items()):
+                    for kern in ("k_lsi", "k_pip"):
+                        v = per_kernel.get(kern)
+                        if v:
+                            f.write("%s,%s,%d,%.0f\n" % (counter, kern, len(v), sum(v) / len(v)))
     acc = collect(fetch_dir)
     for k, v in collect(write_dir).items():
         acc[k].update(v)
