@@ -5,8 +5,13 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _latest_bench():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_f_bench.json")))
+    d = json.load(open(_latest_bench()))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
