@@ -129,6 +129,22 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
                        int32_t* face_id_dev);
 
 /* ---- multi-GPU: RCCL over xGMI ---------------------------------------------------------- */
+/* ---- -mode=grid on the device (the reference's third index, for the grid / lbvh / rt comparison)
+ * replaces: UniformGrid::AddMapsToGrid / AddMapToGrid (src/grid/uniform_grid.h:132-349): one CSR per
+ * map over grid_size x grid_size cells of the scaled domain (calculate_cell, src/grid/cell.h:16-22);
+ * inside a cell the eids are ascending.  Costs one entry per (cell, edge) incidence; fails with
+ * RJ_E_INVALID when those exceed 2^32 (grid too fine for the map's longest edges). */
+int rj_build_grid(rj_handle h, int map_id, int grid_size);
+/* replaces: LSIGrid::Query + intersect_one_cell (src/app/lsi_grid.h:19-131): needs the grids of BOTH
+ * maps at the same grid_size; every cell tests its (map-0 edge, map-1 edge) pairs and reports a hit
+ * only from the cell that contains the computed intersection point.  Output and overflow behaviour
+ * as rj_lsi_query. */
+int rj_lsi_query_grid(rj_handle h, uint64_t capacity, uint32_t* pairs_dev, uint64_t* n_found);
+/* replaces: PIPGrid::Query (src/app/pip_grid.h:37-70, cell acceptance src/algo/pip.h:98-114): needs
+ * the grid of the base map.  Arguments and outputs as rj_pip_query. */
+int rj_pip_query_grid(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
+                      uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev);
+
 /* New design (the reference is single-GPU: no NCCL/MPI anywhere).  One process and
  * one handle per GPU; the query map is sharded by chain range (rj_lsi_query's eid range / the point
  * range of rj_pip_query), the base map + LBVH are replicated, and the result queues are exchanged

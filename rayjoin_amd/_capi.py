@@ -47,6 +47,9 @@ SYMBOLS = {
     "rj_overlay_edge_xsects": (_int, [_vp, _int, _vp, _u64, _vp]),
     "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
+    "rj_build_grid": (_int, [_vp, _int, _int]),
+    "rj_lsi_query_grid": (_int, [_vp, _u64, _vp, C.POINTER(_u64)]),
+    "rj_pip_query_grid": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_last_ms": (_int, [_vp, _int, C.POINTER(C.c_float)]),
     "rj_last_stats": (_int, [_vp, C.POINTER(_u64)]),
     "rj_set_option": (_int, [_vp, C.c_char_p, _i64]),
@@ -224,6 +227,21 @@ class Handle:
             raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
         self._check(rc)
         return n.value
+
+    def build_grid(self, map_id, grid_size):
+        self._check(self.L.rj_build_grid(self.h, map_id, grid_size))
+
+    def lsi_query_grid(self, capacity, pairs_dev):
+        n = _u64()
+        rc = self.L.rj_lsi_query_grid(self.h, capacity, _ptr(pairs_dev), C.byref(n))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
+        self._check(rc)
+        return n.value
+
+    def pip_query_grid(self, base_map_id, query_map_id, pts_dev, pt_begin, n, closest_dev, face_dev=None):
+        self._check(self.L.rj_pip_query_grid(self.h, base_map_id, query_map_id, _ptr(pts_dev), pt_begin, n,
+                                             _ptr(closest_dev), _ptr(face_dev)))
 
     def lsi_count_to(self, n_found_dev):
         """device-side Queue::size: copy the last async LSI's count (u64) to device memory, on the stream"""

@@ -42,6 +42,15 @@ struct BvhState {
   int top = 0;
 };
 
+struct GridState {  // -mode=grid: one CSR per map (rj_grid.hip)
+  bool built = false;
+  int g = 0;
+  double scale = 0;
+  uint32_t* begin = nullptr;  // [g*g + 1]
+  uint32_t* eids = nullptr;   // [total], ascending inside a cell
+  uint64_t total = 0;
+};
+
 constexpr int kNumTimers = 6;
 // average (w + h) of a 64-query group's quantised box above which the query set is re-ordered
 // along the Morton curve before the kernels run (the domain is 2^31 wide per axis)
@@ -61,6 +70,7 @@ struct rj_handle_s {
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
+  GridState grid[2];
   int query_order = 1;  // 0 never, 1 auto (estimate coherence), 2 always
   bool last_ordered = false;
   // coherence decisions for map-owned query sets (immutable after upload): [kind 0=segs,1=points][map]
@@ -117,6 +127,11 @@ int dev_alloc(rj_handle h, T** p, uint64_t count) {
 void free_map(MapState& m) {
   (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.left); (void) hipFree(m.right);
   m = MapState();
+}
+
+void free_grid(GridState& g) {
+  (void) hipFree(g.begin); (void) hipFree(g.eids);
+  g = GridState();
 }
 
 void free_bvh(BvhState& b) {
@@ -181,7 +196,7 @@ int rj_destroy(rj_handle h) {
   RJ_CHECK_H(h);
   (void) hipSetDevice(h->device);
   (void) hipStreamSynchronize(h->stream);
-  for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); }
+  for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
@@ -255,6 +270,7 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   MapState& m = h->map[map_id];
   free_map(m);
   free_bvh(h->bvh[map_id]);
+  free_grid(h->grid[map_id]);
   h->coh[0][map_id].valid = h->coh[1][map_id].valid = false;
   m.np = np; m.nc = nc; m.ne = np - nc;
   if (int r = dev_alloc(h, &m.pts, 2 * np + 2)) return r;
@@ -576,6 +592,116 @@ int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* 
   if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
+  return RJ_OK;
+}
+
+
+// ---- -mode=grid on the device ------------------------------------------------------------------
+int rj_build_grid(rj_handle h, int map_id, int grid_size) {
+  RJ_CHECK_H(h);
+  if (map_id < 0 || map_id > 1 || !h->map[map_id].present) return fail(h, RJ_E_INVALID, "rj_build_grid: map %d not uploaded", map_id);
+  if (grid_size < 1 || grid_size > 32768) return fail(h, RJ_E_INVALID, "rj_build_grid: grid_size must be in [1, 32768]");
+  if (int r = set_device(h)) return r;
+  const MapState& m = h->map[map_id];
+  GridState& gr = h->grid[map_id];
+  free_grid(gr);
+  const uint64_t ncells = (uint64_t) grid_size * grid_size;
+  // cell.h:16-22: scale = grid_size / (INTERNAL_MAX - INTERNAL_MIN) * 0.999, in double, once
+  const double scale = (double) grid_size / (double) ((((int64_t) 1 << 46) - 1) + ((int64_t) 1 << 46)) * 0.999;
+  tic(h, RJ_T_BUILD);
+  uint32_t* counts = nullptr;
+  uint64_t *keys = nullptr, *keys2 = nullptr;
+  void* temp = nullptr;
+  int rc = RJ_OK;
+  hipError_t e = hipSuccess;
+  do {
+    if ((rc = dev_alloc(h, &counts, ncells + 1))) break;
+    if ((rc = dev_alloc(h, &gr.begin, ncells + 1))) break;
+    if ((e = hipMemsetAsync(counts, 0, (ncells + 1) * 4, h->stream)) != hipSuccess) break;
+    if ((e = hipMemsetAsync(h->d_counter + 2, 0, 16, h->stream)) != hipSuccess) break;
+    if ((e = launch_grid_count(h->stream, m.seg, m.ne, grid_size, scale, counts, h->d_counter + 2)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(h->h_pinned + 26, h->d_counter + 2, 8, hipMemcpyDeviceToHost, h->stream)) != hipSuccess) break;
+    if ((e = hipStreamSynchronize(h->stream)) != hipSuccess) break;
+    gr.total = h->h_pinned[26];
+    if (gr.total >= 0xFFFFFFFFull) {
+      rc = fail(h, RJ_E_INVALID, "rj_build_grid: %llu (cell, edge) incidences do not fit 32-bit offsets: use a coarser grid",
+                (unsigned long long) gr.total);
+      break;
+    }
+    size_t scan_bytes = 0, sort_bytes = 0;
+    if ((e = scan_cell_counts(h->stream, nullptr, scan_bytes, counts, gr.begin, ncells + 1)) != hipSuccess) break;
+    if (gr.total && (e = sort_keys_u64(h->stream, nullptr, sort_bytes, (const uint64_t*) nullptr, (uint64_t*) nullptr, gr.total)) != hipSuccess) break;
+    const size_t temp_bytes = scan_bytes > sort_bytes ? scan_bytes : sort_bytes;
+    if ((e = hipMalloc(&temp, temp_bytes ? temp_bytes : 1)) != hipSuccess) break;
+    size_t tb = temp_bytes;
+    if ((e = scan_cell_counts(h->stream, temp, tb, counts, gr.begin, ncells + 1)) != hipSuccess) break;
+    if ((rc = dev_alloc(h, &gr.eids, gr.total ? gr.total : 1))) break;
+    if (gr.total) {
+      if ((rc = dev_alloc(h, &keys, gr.total))) break;
+      if ((rc = dev_alloc(h, &keys2, gr.total))) break;
+      if ((e = launch_grid_emit(h->stream, m.seg, m.ne, grid_size, scale, keys, h->d_counter + 3)) != hipSuccess) break;
+      tb = temp_bytes;
+      if ((e = sort_keys_u64(h->stream, temp, tb, keys, keys2, gr.total)) != hipSuccess) break;
+      if ((e = launch_grid_unpack(h->stream, keys2, gr.total, gr.eids)) != hipSuccess) break;
+    }
+    toc(h, RJ_T_BUILD);
+    e = hipStreamSynchronize(h->stream);
+  } while (0);
+  (void) hipFree(counts); (void) hipFree(keys); (void) hipFree(keys2); (void) hipFree(temp);
+  if (rc) { free_grid(gr); return rc; }
+  if (e != hipSuccess) free_grid(gr);
+  RJ_HIP(h, e);
+  gr.g = grid_size;
+  gr.scale = scale;
+  gr.built = true;
+  return RJ_OK;
+}
+
+int rj_lsi_query_grid(rj_handle h, uint64_t capacity, uint32_t* pairs_dev, uint64_t* n_found) {
+  RJ_CHECK_H(h);
+  const GridState &g0 = h->grid[0], &g1 = h->grid[1];
+  if (!g0.built || !g1.built || g0.g != g1.g)
+    return fail(h, RJ_E_INVALID, "rj_lsi_query_grid: call rj_build_grid for both maps with the same grid_size first");
+  if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query_grid: null output");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear
+  GridLsiArgs a;
+  a.g = g0.g; a.scale = g0.scale;
+  a.begin0 = g0.begin; a.eids0 = g0.eids; a.begin1 = g1.begin; a.eids1 = g1.eids;
+  a.seg0 = h->map[0].seg; a.seg1 = h->map[1].seg;
+  a.out = pairs_dev; a.cap = capacity; a.counter = h->d_counter;
+  tic(h, RJ_T_LSI_KERNEL);
+  RJ_HIP(h, launch_lsi_grid(h->stream, a));
+  toc(h, RJ_T_LSI_KERNEL);
+  return rj_lsi_query_finish(h, capacity, n_found);
+}
+
+int rj_pip_query_grid(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev, uint64_t pt_begin,
+                      uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev) {
+  RJ_CHECK_H(h);
+  if (base_map_id < 0 || base_map_id > 1 || query_map_id != 1 - base_map_id)
+    return fail(h, RJ_E_INVALID, "rj_pip_query_grid: base/query map ids must be {0,1} and differ");
+  const GridState& gr = h->grid[base_map_id];
+  if (!gr.built) return fail(h, RJ_E_INVALID, "rj_pip_query_grid: call rj_build_grid(base map) first");
+  if (n && !closest_eid_dev) return fail(h, RJ_E_INVALID, "rj_pip_query_grid: null output");
+  const int64_t* pts = pts_dev;
+  if (!pts) {
+    const MapState& q = h->map[query_map_id];
+    if (!q.present || pt_begin + n > q.np) return fail(h, RJ_E_INVALID, "rj_pip_query_grid: bad point range of the query map");
+    pts = q.pts + 2 * pt_begin;
+  }
+  if (int r = set_device(h)) return r;
+  GridPipArgs a;
+  a.g = gr.g; a.scale = gr.scale;
+  a.begin = gr.begin; a.eids = gr.eids;
+  a.base = map_view(h->map[base_map_id]);
+  a.pts = pts; a.n = n;
+  a.query_map_id = query_map_id;
+  a.closest = closest_eid_dev; a.face = face_id_dev;
+  tic(h, RJ_T_PIP_KERNEL);
+  RJ_HIP(h, launch_pip_grid(h->stream, a));
+  toc(h, RJ_T_PIP_KERNEL);
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
   return RJ_OK;
 }
 

@@ -42,6 +42,36 @@ struct PipArgs {
   unsigned long long* stats;
 };
 
+// ---- -mode=grid on the device (rj_grid.hip) ------------------------------------------------
+struct GridLsiArgs {
+  int g;
+  double scale;  // grid_size / INTERNAL_RANGE * 0.999 (cell.h:16-22), computed once on the host
+  const uint32_t *begin0, *eids0, *begin1, *eids1;  // per-map CSR over g*g cells, eids ascending inside a cell
+  const Seg *seg0, *seg1;
+  uint32_t* out;  // (eid map 0, eid map 1) pairs
+  uint64_t cap;
+  unsigned long long* counter;
+};
+struct GridPipArgs {
+  int g;
+  double scale;
+  const uint32_t *begin, *eids;  // the base map's CSR
+  DeviceMap base;
+  const int64_t* pts;
+  uint64_t n;
+  int query_map_id;
+  uint32_t* closest;
+  int32_t* face;  // nullable
+};
+hipError_t launch_grid_count(hipStream_t st, const Seg* seg, uint64_t ne, int g, double scale, uint32_t* counts,
+                             unsigned long long* total);
+hipError_t launch_grid_emit(hipStream_t st, const Seg* seg, uint64_t ne, int g, double scale, uint64_t* keys,
+                            unsigned long long* cursor);
+hipError_t launch_grid_unpack(hipStream_t st, const uint64_t* keys, uint64_t n, uint32_t* eids);
+hipError_t scan_cell_counts(hipStream_t st, void* temp, size_t& temp_bytes, const uint32_t* counts, uint32_t* begin, uint64_t n);
+hipError_t launch_lsi_grid(hipStream_t st, const GridLsiArgs& a);
+hipError_t launch_pip_grid(hipStream_t st, const GridPipArgs& a);
+
 hipError_t launch_build_segs(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin,
                              uint32_t nc, uint64_t ne, Seg* seg, uint32_t* edge_chain);
 hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, MortonKey* keys, uint32_t* vals);

@@ -1,6 +1,7 @@
-// lsi_pip.h -- the reference's query operators for -mode=lbvh over the C ABI.
+// lsi_pip.h -- the reference's query operators for -mode=lbvh and -mode=grid over the C ABI.
 //   LSI  {Init, Query, get_xsects, CopyTo}     src/app/lsi.h:8-43, src/app/lsi_lbvh.h:17-98
 //   PIP  {Init, Query, get_closest_eids}       src/app/pip.h:9-38, src/app/pip_lbvh.h:14-142
+//   LSIGrid / PIPGrid                          src/app/lsi_grid.h:80-131, src/app/pip_grid.h:14-70
 // Same method names, argument meaning and lifetime rules (results stay valid until the next
 // Query or destruction); errors are exceptions carrying the C-ABI status (the reference throws
 // from CUDA_CHECK, src/util/exception.h:150-158); a full queue throws instead of being UB.
@@ -75,6 +76,21 @@ class LSILBVH : public LSI {
   }
 };
 
+// -mode=grid: the uniform grid holds both maps (UniformGrid::AddMapsToGrid); the result does not
+// depend on query_map_id (lsi_grid.h:103-104) and cannot be restricted to an eid range.
+class LSIGrid : public LSI {
+ public:
+  explicit LSIGrid(Context& ctx) : LSI(ctx) {}
+  void Query(int /*query_map_id*/) override {
+    if (ranged_ && !(e0_ == 0 && e1_ == ctx_.get_map(1)->n_edges()))
+      throw RjError(RJ_E_INVALID, "LSIGrid: -mode=grid joins the two whole maps (no shards)");
+    uint64_t n = 0;
+    int rc = rj_lsi_query_grid(ctx_.handle(), cap_, queue_, &n);
+    n_ = n < cap_ ? n : cap_;
+    rj_check(ctx_.handle(), rc, "rj_lsi_query_grid");
+  }
+};
+
 class PIP {
  public:
   explicit PIP(Context& ctx) : ctx_(ctx) {}
@@ -109,6 +125,17 @@ class PIPLBVH : public PIP {
     if (n > cap_) throw RjError(RJ_E_INVALID, "PIP::Query: more points than Init() reserved");
     rj_check(ctx_.handle(), rj_pip_query(ctx_.handle(), 1 - query_map_id, query_map_id, query_points_dev, 0, n,
                                          closest_, faces_), "rj_pip_query");
+    n_ = n;
+  }
+};
+
+class PIPGrid : public PIP {
+ public:
+  explicit PIPGrid(Context& ctx) : PIP(ctx) {}
+  void Query(int query_map_id, const int64_t* query_points_dev, size_t n) override {
+    if (n > cap_) throw RjError(RJ_E_INVALID, "PIP::Query: more points than Init() reserved");
+    rj_check(ctx_.handle(), rj_pip_query_grid(ctx_.handle(), 1 - query_map_id, query_map_id, query_points_dev, 0, n,
+                                              closest_, faces_), "rj_pip_query_grid");
     n_ = n;
   }
 };

@@ -1,9 +1,8 @@
 // query_exec -- RayJoin's LSI / PIP benchmark driver (src/query.cc, src/run_query.cu) with the
 // MI355X-native -mode=lbvh path behind it.  Same flags, same phases, same stderr timing format.
 //   -mode=lbvh : software LBVH in hand-written HIP (this repository)
+//   -mode=grid : the reference's uniform grid, also in HIP (rj_grid.hip), -grid_size as in src/flags.cc
 //   -mode=rt   : rejected -- gfx950 has no ray-tracing units (the reference's OptiX path)
-//   -mode=grid : rejected here -- the uniform-grid algorithm exists in this repository only as
-//                the CPU parity oracle (oracle/, test infrastructure), never as a product path
 #include <unistd.h>
 
 #include <cstdio>
@@ -21,7 +20,7 @@ using namespace rayjoin;
 namespace {
 
 void Usage(const char* argv0) {
-  std::cerr << "Usage: " << argv0 << " -poly1 <base.cdb> [-poly2 <query.cdb>] -query lsi|pip -mode lbvh\n"
+  std::cerr << "Usage: " << argv0 << " -poly1 <base.cdb> [-poly2 <query.cdb>] -query lsi|pip -mode lbvh|grid [-grid_size 2048]\n"
             << "  [-serialize <dir>] [-xsect_factor 0.2] [-warmup 5] [-repeat 5] [-seed N] [-gen_n 10000]\n"
             << "  [-gen_t 0.1] [-output <pairs.txt>] [-device 0] [-v 1]\n"
             << "  [-sample map|edges -sample_map_id 0|1 -sample_rate 0.5 [-sample_output <map.bin>]]\n";
@@ -103,9 +102,8 @@ void ApplySampling(const Flags& f, std::shared_ptr<PlanarGraph>& base, std::shar
 }
 
 void CheckMode(const Flags& f) {
-  if (f.mode == "lbvh") return;
+  if (f.mode == "lbvh" || f.mode == "grid") return;
   if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
-  if (f.mode == "grid") throw std::runtime_error("-mode=grid is the CPU parity oracle of this repository (oracle/), not a product path: use -mode=lbvh");
   throw std::runtime_error("Invalid index type: " + f.mode);
 }
 
@@ -128,7 +126,10 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
     ctx.reset(new Context({base, query}, f.device));
   }
   tm.next("Create App");
-  LSILBVH lsi(*ctx);
+  const bool grid = f.mode == "grid";
+  if (grid && f.nranks > 1) throw std::invalid_argument("-mode=grid joins the two whole maps: no -nranks");
+  std::unique_ptr<LSI> lsi_p(grid ? (LSI*) new LSIGrid(*ctx) : (LSI*) new LSILBVH(*ctx));
+  LSI& lsi = *lsi_p;
   tm.next("Load Data");
   ctx->LoadToDevice();
   if (gen_queries) ctx->set_map(1, gen_queries);
@@ -144,7 +145,12 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
   }
   lsi.set_query_range(e0, e1);
   tm.next("Build Index");
-  rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
+  if (grid) {  // run_query.cu:247-249: AddMapsToGrid
+    rj_check(ctx->handle(), rj_build_grid(ctx->handle(), 0, f.grid_size), "rj_build_grid");
+    rj_check(ctx->handle(), rj_build_grid(ctx->handle(), 1, f.grid_size), "rj_build_grid");
+  } else {
+    rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
+  }
   tm.next("Warmup");
   for (int i = 0; i < f.warmup; i++) lsi.Query(1);
   tm.next("Query", f.repeat);
@@ -204,11 +210,16 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
     n_points = ctx->get_map(1)->n_points();
   }
   tm.next("Create App");
-  PIPLBVH pip(*ctx);
+  const bool grid = f.mode == "grid";
+  std::unique_ptr<PIP> pip_p(grid ? (PIP*) new PIPGrid(*ctx) : (PIP*) new PIPLBVH(*ctx));
+  PIP& pip = *pip_p;
   tm.next("Init");
   pip.Init(n_points);
   tm.next("Build Index");
-  rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
+  if (grid)  // run_query.cu:381: AddMapToGrid(ctx, 0)
+    rj_check(ctx->handle(), rj_build_grid(ctx->handle(), 0, f.grid_size), "rj_build_grid");
+  else
+    rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
   tm.next("Warmup");
   for (int i = 0; i < f.warmup; i++) pip.Query(1, d_pts, n_points);
   tm.next("Query", f.repeat);

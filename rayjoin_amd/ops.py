@@ -1,4 +1,4 @@
-"""Host-side mirror of the reference's query operators for -mode=lbvh, on top of the C ABI.
+"""Host-side mirror of the reference's query operators for -mode=lbvh (and -mode=grid), on top of the C ABI.
 
   LSILBVH(ctx).Init(max_n_xsects); .Query(query_map_id); .get_xsects(); .CopyTo()
       -- src/app/lsi.h:8-43, src/app/lsi_lbvh.h:17-98
@@ -6,6 +6,9 @@
       -- src/app/pip.h:9-38, src/app/pip_lbvh.h:14-142
   DeviceContext.LoadToDevice()/BuildIndex()
       -- src/context.h:76-88, src/run_query.cu:273-290 ("Build Index")
+
+  LSIGrid / PIPGrid + DeviceContext.BuildGrid(grid_size): the uniform-grid operators
+      -- src/app/lsi_grid.h:80-131, src/app/pip_grid.h:14-70, src/grid/uniform_grid.h:132-349
 
 Same names, argument meaning and error behaviour, with two deliberate differences recorded in
 DESIGN.md: LSI pairs are always evaluated as (e1 = map-0 edge, e2 = map-1 edge) so results
@@ -40,6 +43,14 @@ class DeviceContext:
         self.handle.build_lbvh(base_map_id)
         self.indexed[base_map_id] = True
         return self.handle.last_ms(_capi.RJ_T_BUILD)
+
+    def BuildGrid(self, grid_size, map_ids=(0, 1)):
+        """UniformGrid::AddMapsToGrid (both maps, LSI) / AddMapToGrid (base map only, PIP)."""
+        ms = 0.0
+        for im in map_ids:
+            self.handle.build_grid(im, grid_size)
+            ms += self.handle.last_ms(_capi.RJ_T_BUILD)
+        return ms
 
     def get_map(self, im):
         return self.ctx.get_map(im)
@@ -128,3 +139,40 @@ class PIPLBVH:
 
     def get_face_ids(self):
         return self.faces.to_host(np.int32, self.n)
+
+
+class LSIGrid(LSILBVH):
+    """-mode=grid LSI (src/app/lsi_grid.h): needs DeviceContext.BuildGrid(g) for both maps.
+    The grid holds both maps, so the result does not depend on query_map_id and there is no
+    eid sub-range (the reference's LSIGrid::Query ignores its query_map_id too, lsi_grid.h:103-104)."""
+
+    def Query(self, query_map_id=1, eid_range=None):
+        if eid_range is not None:
+            raise ValueError("LSIGrid has no eid sub-ranges: the grid joins the two whole maps")
+        try:
+            self.n_xsects = self.h.lsi_query_grid(self.capacity, self.queue)
+        except _capi.QueueOverflow as e:
+            self.n_xsects = min(e.n_found, self.capacity)
+            raise
+        return self.n_xsects
+
+
+class PIPGrid(PIPLBVH):
+    """-mode=grid PIP (src/app/pip_grid.h): needs DeviceContext.BuildGrid(g, (base_map_id,))."""
+
+    def Query(self, query_map_id, query_points=None, point_range=None):
+        base = 1 - query_map_id
+        if query_points is not None:
+            pts = np.ascontiguousarray(query_points, dtype=np.int64).reshape(-1, 2)
+            n = pts.shape[0]
+            buf = self.h.alloc(16 * max(1, n)).from_host(pts)
+            assert n <= self.n_alloc
+            self.h.pip_query_grid(base, query_map_id, buf, 0, n, self.closest, self.faces)
+            buf.free()
+        else:
+            b, e = point_range if point_range is not None else (0, self.ctx_.get_map(query_map_id).n_points)
+            n = e - b
+            assert n <= self.n_alloc
+            self.h.pip_query_grid(base, query_map_id, None, b, n, self.closest, self.faces)
+        self.n = n
+        return n

@@ -42,6 +42,17 @@ def test_query_exec_lsi_and_pip(oracle, tmp_path):
     got = np.loadtxt(outp, dtype=np.int64).reshape(-1, 2)
     assert np.array_equal(got[:, 0].astype(np.uint32), eids)
     assert np.array_equal(got[:, 1].astype(np.int32), m0.face_ids(eids))
+    # -mode=grid: the same answers from the device-side uniform grid (the three-way comparison)
+    outg = str(tmp_path / "pairs_grid.txt")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "grid", "-grid_size", "512",
+                        "-xsect_factor", "0.5", "-warmup", "1", "-repeat", "1", "-output", outg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(outg).read() == open(out).read()
+    outpg = str(tmp_path / "pip_grid.txt")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "pip", "-mode", "grid", "-grid_size", "512",
+                        "-warmup", "0", "-repeat", "1", "-output", outpg], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(outpg).read() == open(outp).read()
     # generated workloads (no -poly2) run and overflow is a reported error, not UB
     r = subprocess.run([EXE, "-poly1", p0, "-query", "lsi", "-mode", "lbvh", "-gen_n", "2000", "-gen_t", "5",
                         "-seed", "3", "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)

@@ -24,8 +24,12 @@ def test_usage_and_flag_errors(exe):
     assert r.returncode == 1 and "Usage" in r.stderr  # query.cc:13-16
     r = subprocess.run([exe, "-poly1", "x.cdb", "-query", "lsi", "-mode", "rt"], capture_output=True, text=True)
     assert r.returncode == 3 and "no" in r.stderr and "lbvh" in r.stderr
-    r = subprocess.run([exe, "-poly1", "x.cdb", "-query", "lsi", "-mode", "grid"], capture_output=True, text=True)
-    assert r.returncode == 3 and "oracle" in r.stderr
+    # -mode=grid is a device mode too (rj_grid.hip); it gets as far as the missing file
+    r = subprocess.run([exe, "-poly1", "/nonexistent.cdb", "-query", "lsi", "-mode", "grid", "-grid_size", "64"],
+                       capture_output=True, text=True)
+    assert r.returncode == 3 and "Cannot open file" in r.stderr
+    r = subprocess.run([exe, "-poly1", "x.cdb", "-query", "lsi", "-mode", "quadtree"], capture_output=True, text=True)
+    assert r.returncode == 3 and "Invalid index type" in r.stderr
     r = subprocess.run([exe, "-poly1=x.cdb", "-query=lsi", "-mode=lbvh", "-bogus=1"], capture_output=True, text=True)
     assert r.returncode == 2 and "unknown command line flag" in r.stderr
     r = subprocess.run([exe, "-poly1", "x.cdb", "-query", "nn", "-mode", "lbvh"], capture_output=True, text=True)
