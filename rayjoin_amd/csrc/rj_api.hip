@@ -805,7 +805,8 @@ int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint6
   RJ_CHECK_H(h);
   if (im < 0 || im > 1) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: im must be 0 or 1");
   if (!h->map[0].present || !h->map[1].present) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: both maps must be uploaded");
-  if (!h->bvh[1 - im].built) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: call rj_build_lbvh(%d) first (mid-points are located in the other map)", 1 - im);
+  if (!h->bvh[1 - im].built && !h->grid[1 - im].built)
+    return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: call rj_build_lbvh(%d) or rj_build_grid(%d, g) first (mid-points are located in the other map)", 1 - im, 1 - im);
   if (n && (!pairs_dev || !xsects_dev)) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: null buffer");
   if (n == 0) return RJ_OK;
   if (n >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_overlay_edge_xsects: too many intersections");
@@ -844,7 +845,10 @@ int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint6
     if ((e = launch_xsect_gather(h->stream, tmp, vout, n, (XsectRec*) xsects_dev)) != hipSuccess) break;
     if ((e = launch_xsect_order_runs(h->stream, (XsectRec*) xsects_dev, n, im, h->map[im].seg, mid)) != hipSuccess) break;
     // 4. locate the mid-points in the other map (query map id = im, map_overlay_lbvh.h:232-236)
-    if ((rc = rj_pip_query_async(h, 1 - im, im, mid, 0, n, closest, face))) break;
+    // (through the LBVH of the other map when there is one, else through its grid: MapOverlayGrid)
+    if (h->bvh[1 - im].built) rc = rj_pip_query_async(h, 1 - im, im, mid, 0, n, closest, face);
+    else rc = rj_pip_query_grid(h, 1 - im, im, mid, 0, n, closest, face);
+    if (rc) break;
     if ((e = launch_xsect_set_mid(h->stream, (XsectRec*) xsects_dev, n, im, face)) != hipSuccess) break;
     e = hipStreamSynchronize(h->stream);
   } while (0);

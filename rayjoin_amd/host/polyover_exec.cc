@@ -2,6 +2,8 @@
 // on the MI355X-native LSI / PIP path.  Same flags, phases and stderr timing format.
 //   MapOverlayLBVH::{Init, BuildIndex, IntersectEdge, LocateVerticesInOtherMap,
 //                    ComputeOutputPolygons, WriteResult}     src/app/map_overlay_lbvh.h:25-270
+//   -mode=grid (MapOverlayGrid, src/app/map_overlay_grid.h) runs the same stages on the device-side
+//   uniform grid; -check compares the LBVH results with the grid's, as run_overlay.cu:18-141 does.
 #include <iostream>
 
 #include "context.h"
@@ -15,7 +17,8 @@ namespace {
 
 class MapOverlayLBVH {
  public:
-  MapOverlayLBVH(Context& ctx, double xsect_factor) : ctx_(ctx), xsect_factor_(xsect_factor) {}
+  MapOverlayLBVH(Context& ctx, double xsect_factor, bool grid = false, int grid_size = 2048)
+      : ctx_(ctx), xsect_factor_(xsect_factor), grid_(grid), grid_size_(grid_size) {}
   ~MapOverlayLBVH() {
     rj_handle h = ctx_.handle();
     if (pairs_) rj_dev_free(h, pairs_);
@@ -35,21 +38,28 @@ class MapOverlayLBVH {
       rj_check(h, rj_dev_alloc(h, 4 * (np ? np : 1), (void**) &faces_[im]), "rj_dev_alloc");
     }
   }
-  void BuildIndex() {  // :42-58: an LBVH over each map
-    for (int im = 0; im < 2; im++) rj_check(ctx_.handle(), rj_build_lbvh(ctx_.handle(), im), "rj_build_lbvh");
+  void BuildIndex() {  // :42-58: an LBVH over each map (grid mode: AddMapsToGrid)
+    for (int im = 0; im < 2; im++) {
+      if (grid_) rj_check(ctx_.handle(), rj_build_grid(ctx_.handle(), im, grid_size_), "rj_build_grid");
+      else rj_check(ctx_.handle(), rj_build_lbvh(ctx_.handle(), im), "rj_build_lbvh");
+    }
   }
   void IntersectEdge(int query_map_id) {  // :60-71
     uint64_t n = 0;
-    int rc = rj_lsi_query(ctx_.handle(), 1 - query_map_id, query_map_id, 0, ctx_.get_map(query_map_id)->n_edges(), cap_,
-                          pairs_, &n);
+    int rc = grid_ ? rj_lsi_query_grid(ctx_.handle(), cap_, pairs_, &n)
+                   : rj_lsi_query(ctx_.handle(), 1 - query_map_id, query_map_id, 0,
+                                  ctx_.get_map(query_map_id)->n_edges(), cap_, pairs_, &n);
     rj_check(ctx_.handle(), rc, "rj_lsi_query");
     n_xsects_ = n;
     std::cerr << "Intersections: " << n << std::endl;
   }
   void LocateVerticesInOtherMap(int query_map_id) {  // :73-107
+    const size_t np = ctx_.get_map(query_map_id)->n_points();
     rj_check(ctx_.handle(),
-             rj_pip_query(ctx_.handle(), 1 - query_map_id, query_map_id, nullptr, 0, ctx_.get_map(query_map_id)->n_points(),
-                          closest_[query_map_id], faces_[query_map_id]),
+             grid_ ? rj_pip_query_grid(ctx_.handle(), 1 - query_map_id, query_map_id, nullptr, 0, np,
+                                       closest_[query_map_id], faces_[query_map_id])
+                   : rj_pip_query(ctx_.handle(), 1 - query_map_id, query_map_id, nullptr, 0, np,
+                                  closest_[query_map_id], faces_[query_map_id]),
              "rj_pip_query");
   }
   void ComputeOutputPolygons() {  // :109-265
@@ -72,15 +82,17 @@ class MapOverlayLBVH {
     }
     WriteOutputChain(ctx_, xsects_, pip, path);
   }
-  // self-check that needs no second implementation: the pair set must not depend on which map is
-  // indexed, because the predicate is always evaluated as (map-0 edge, map-1 edge)
-  bool CheckRoleSymmetry() {
+  // CheckResult (run_overlay.cu:18-141): the same stages through -mode=grid must give the same
+  // intersections and the same located edges.  Runs the device-side grid next to the LBVH results.
+  bool CheckAgainstGrid(int grid_size) {
     rj_handle h = ctx_.handle();
+    bool ok = true;
+    for (int im = 0; im < 2; im++) rj_check(h, rj_build_grid(h, im, grid_size), "rj_build_grid");
     uint32_t* p2 = nullptr;
     rj_check(h, rj_dev_alloc(h, 8 * (cap_ ? cap_ : 1), (void**) &p2), "rj_dev_alloc");
     uint64_t n2 = 0;
-    int rc = rj_lsi_query(h, 0, 1, 0, ctx_.get_map(1)->n_edges(), cap_, p2, &n2);
-    bool ok = rc == RJ_OK && n2 == n_xsects_;
+    int rc = rj_lsi_query_grid(h, cap_, p2, &n2);
+    ok = rc == RJ_OK && n2 == n_xsects_;
     if (ok) {
       std::vector<uint32_t> a(2 * n2), b(2 * n2);
       rj_sort_pairs(h, p2, n2);
@@ -90,12 +102,27 @@ class MapOverlayLBVH {
       ok = a == b;
     }
     rj_dev_free(h, p2);
+    std::cerr << (ok ? "LSI passed check" : "LSI check FAILED") << std::endl;
+    for (int im = 0; im < 2 && ok; im++) {
+      const size_t np = ctx_.get_map(im)->n_points();
+      uint32_t* c2 = nullptr;
+      rj_check(h, rj_dev_alloc(h, 4 * (np ? np : 1), (void**) &c2), "rj_dev_alloc");
+      rc = rj_pip_query_grid(h, 1 - im, im, nullptr, 0, np, c2, nullptr);
+      std::vector<uint32_t> a(np), b(np);
+      rj_memcpy_d2h(h, a.data(), c2, 4 * np);
+      rj_memcpy_d2h(h, b.data(), closest_[im], 4 * np);
+      rj_dev_free(h, c2);
+      ok = rc == RJ_OK && a == b;
+      std::cerr << "Map " << im << (ok ? ": PIP passed check" : ": PIP check FAILED") << std::endl;
+    }
     return ok;
   }
 
  private:
   Context& ctx_;
   double xsect_factor_;
+  bool grid_;
+  int grid_size_;
   size_t cap_ = 0, n_xsects_ = 0;
   uint32_t* pairs_ = nullptr;
   uint32_t* closest_[2] = {nullptr, nullptr};
@@ -112,7 +139,7 @@ void RunOverlay(const Flags& f) {  // run_overlay.cu:143-228
   auto g2 = load_from(f.poly2, f.serialize, f.v);
   tm.next("Create App");
   Context ctx({g1, g2}, f.device);
-  MapOverlayLBVH overlay(ctx, f.xsect_factor);
+  MapOverlayLBVH overlay(ctx, f.xsect_factor, f.mode == "grid", f.grid_size);
   tm.next("Load Data");
   ctx.LoadToDevice();
   tm.next("Init");
@@ -127,12 +154,9 @@ void RunOverlay(const Flags& f) {  // run_overlay.cu:143-228
   }
   tm.next("Computer output polygons");
   overlay.ComputeOutputPolygons();
-  if (f.check) {
-    // the reference re-runs -mode=grid here (run_overlay.cu:18-141); the grid algorithm exists in
-    // this repository only as the test oracle, so the product checks a property instead
+  if (f.check && f.mode != "grid") {  // run_overlay.cu:199-204: compare with -mode=grid
     tm.next("Check result");
-    if (overlay.CheckRoleSymmetry()) std::cerr << "LSI passed check (role symmetry)" << std::endl;
-    else throw std::runtime_error("LSI role-symmetry check FAILED");
+    if (!overlay.CheckAgainstGrid(f.grid_size)) throw std::runtime_error("result differs from -mode=grid");
   }
   if (!f.output.empty()) {
     tm.next("Write to file");
@@ -145,7 +169,7 @@ void RunOverlay(const Flags& f) {  // run_overlay.cu:143-228
 
 int main(int argc, char* argv[]) {
   if (argc == 1) {
-    std::cerr << "Usage: " << argv[0] << " -poly1 <map0.cdb> -poly2 <map1.cdb> -mode lbvh [-output <result.cdb>]\n"
+    std::cerr << "Usage: " << argv[0] << " -poly1 <map0.cdb> -poly2 <map1.cdb> -mode lbvh|grid [-grid_size 2048] [-output <result.cdb>]\n"
               << "  [-serialize <dir>] [-xsect_factor 0.2] [-check] [-device 0] [-v 1]\n";
     return 1;
   }
@@ -154,8 +178,7 @@ int main(int argc, char* argv[]) {
     f.Parse(argc, argv);
     if (f.poly1.empty() || f.poly2.empty()) throw std::invalid_argument("-poly1 and -poly2 are required");
     if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
-    if (f.mode == "grid") throw std::runtime_error("-mode=grid is the CPU parity oracle of this repository (oracle/), not a product path: use -mode=lbvh");
-    if (f.mode != "lbvh") throw std::runtime_error("Illegal mode: " + f.mode);
+    if (f.mode != "lbvh" && f.mode != "grid") throw std::runtime_error("Illegal mode: " + f.mode);
     RunOverlay(f);
   } catch (const std::invalid_argument& e) {
     std::cerr << "ERROR: " << e.what() << std::endl;
