@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-scale", type=float, default=1.0)
     ap.add_argument("--check", action="store_true", help="size-independent result checks after timing")
     ap.add_argument("--gather-pip", action="store_true", help="N>1: also all-gather the PIP result queues every step")
+    ap.add_argument("--serial-kernels", action="store_true", help="run the PIP kernel after the LSI kernel instead of beside it")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="N",
                     help="diagnostic, 1 GPU: time rank 0's shard of an N-way run (no exchange); the line is marked as such")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -138,6 +139,8 @@ def main():
     t_upload = time.perf_counter() - t0
     h.build_lbvh(0)
     h.build_lbvh(0)  # second build = steady-state allocator
+    if not args.serial_kernels:
+        h.set_option("pip_concurrent", 2)  # LSI and PIP of a step are independent: small shards let them overlap
     build_ms = h.last_ms(_capi.RJ_T_BUILD)
 
     # ---- shard the query map by chain range -------------------------------------
@@ -169,6 +172,7 @@ def main():
             n = state["cnt_all"][rank]
         else:
             n = h.lsi_query_finish(cap)
+        h.sync()  # joins the PIP kernel, which runs on the handle's second stream beside the LSI kernel
         if record:
             lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
             pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))

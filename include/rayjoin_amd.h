@@ -200,7 +200,11 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
  * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
  * consecutive queries are spatially scattered, e.g. the generated workloads of
- * src/run_query.cu:102-167) / 2 always. */
+ * src/run_query.cu:102-167) / 2 always.   "pip_concurrent" 0 never (default) / 1 always / 2 auto (only for
+ * query sets small enough to leave the chip partly idle): rj_pip_query_async launches on a second
+ * stream owned by the handle, so the PIP kernel overlaps work on the main stream (the LSI kernel of
+ * the same step: both only read the maps and the index).  Its inputs must be complete when the call
+ * is made; its outputs are complete after rj_sync, rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL). */
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 
 /* ---- device memory helpers (for hosts without their own allocator) -------------------- */

@@ -173,6 +173,36 @@ def test_query_ordering_modes_agree(oracle, lattice_pair):
     assert h.last_ms(_capi.RJ_T_ORDER) > 0  # the always-mode ran the ordering pass
 
 
+def test_pip_on_the_second_stream_beside_lsi(oracle, lattice_pair):
+    """rj_set_option "pip_concurrent": the PIP kernel runs on the handle's second stream while the
+    LSI kernel runs on the main one; both results are those of the serial calls."""
+    ctx, dctx = lattice_pair
+    h = dctx.handle
+    m0 = _omap(oracle, ctx.maps[0])
+    want_pairs = oracle.lsi_brute(m0, _omap(oracle, ctx.maps[1]))
+    want_eids = oracle.pip_brute(m0, 1, ctx.maps[1].pts)
+    cap = 4 * len(want_pairs)
+    pairs = h.alloc(8 * cap)
+    closest = h.alloc(4 * ctx.maps[1].n_points)
+    faces = h.alloc(4 * ctx.maps[1].n_points)
+    try:
+        for mode in (1, 2):
+            h.set_option("pip_concurrent", mode)
+            for _ in range(3):
+                h.lsi_query_async(0, 1, 0, ctx.maps[1].n_edges, cap, pairs)
+                h.pip_query(0, 1, None, 0, ctx.maps[1].n_points, closest, faces, sync=False)
+                n = h.lsi_query_finish(cap)
+                h.sync()
+                assert n == len(want_pairs)
+                assert np.array_equal(closest.to_host(np.uint32), want_eids)
+                assert np.array_equal(faces.to_host(np.int32), m0.face_ids(want_eids))
+            h.sort_pairs(pairs, n)
+            assert np.array_equal(pairs.to_host(np.uint32, 2 * n).reshape(-1, 2), want_pairs)
+            assert h.last_ms(_capi.RJ_T_PIP_KERNEL) > 0 and h.last_ms(_capi.RJ_T_LSI_KERNEL) > 0
+    finally:
+        h.set_option("pip_concurrent", 0)
+
+
 def test_two_handles_from_two_threads(oracle, lattice_pair):
     """A handle is not thread-safe, but different handles may be used from different threads
     (include/rayjoin_amd.h conventions); ctypes drops the GIL during the calls."""
