@@ -3,7 +3,7 @@
 //
 // LBVH layout (replaces deps/lbvh's pointer-based binary Karras tree, deps/lbvh/lbvh/bvh.cuh:
 // tree shape does not affect results, only the exact predicate does -- SURVEY fact 8):
-//   * base segments are sorted by a 64-bit 2-D Morton key of their midpoint (y is the
+//   * base segments are sorted by a 2-D Morton key of their midpoint (32 bits kept; y is the
 //     most significant interleaved bit so the first children of a node are its low-y half);
 //   * level 0 = the sorted segments, level l = groups of 64 consecutive level-(l-1) nodes:
 //     a 64-ary, pointer-free, implicit tree.  Node i of level l covers children

@@ -48,7 +48,8 @@ __device__ __forceinline__ uint64_t spread32(uint32_t v) {  // insert a 0 bit be
   return x;
 }
 
-// 64-bit Morton key straight from the int64 midpoint (no float, 32 bits per axis, y is the MSB)
+// Morton key straight from the int64 midpoint (no float; y is the most significant interleaved bit);
+// only its top 64 - kMortonDropBits bits are kept (rj_device.h)
 __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uint64_t ne,
                                                 MortonKey* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
@@ -643,8 +644,10 @@ __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, u
 //     diff_y < 0 with margin), so its box top bounds the lane's best from above;
 //   * candidates go to per-lane lists in LDS ([k][lane]: bank = lane, conflict-free) and are
 //     evaluated exactly by their own lane -- no cross-lane merge;
-//   * the leaf loop runs over whichever side is smaller: relevant base segments (lanes =
-//     points) or relevant points (lanes = base segments).
+//   * leaf blocks are x0-sorted: a lane finds its segments by a cross-lane binary search and a
+//     backward scan bounded by the prefix max of x1 (k_build_leaves);
+//   * the kernel is VALU-issue bound: the exact test computes two 128-bit
+//     products, and the slope only on ties.
 // =============================================================================================
 constexpr int kPipList = 8;     // candidate slots per lane between two exact-evaluation rounds
 constexpr int kPipRefineAbove = 16;  // per-lane check at push time only when more children than this pass the group test

@@ -4,10 +4,11 @@
 //   lsi_test()      dev::intersect_test, boolean form            src/algo/lsi.h:29-103
 //   lsi_point()     intersection point + narrowing store         src/algo/lsi.h:107-143,
 //                                                                 src/util/rational.h:87-90,190-203,335-343
-//   pip_eval()/pip_better()  "lowest edge above point" predicate  src/algo/pip.h:31-96
+//   pip_eval_y()/pip_slope()/pip_better()  "lowest edge above point"  src/algo/pip.h:31-96
 //                                                                 == src/app/pip_lbvh.h:57-123
-// The 80-byte dev::Edge (src/map/map.h:20-46) is never stored: a, b, c are rebuilt from the two
-// endpoints (map.h:216-226), which is cheaper than a 48-byte gather on a latency-bound path.
+// The 80-byte dev::Edge (src/map/map.h:20-46) is never stored: what the predicates need of a, b, c
+// is rebuilt from the two endpoints (map.h:216-226) -- for the two query predicates without ever
+// forming c (see edge_side and pip_eval_y).
 //
 // RJ_HD lets tests compile these functions for the host (tests/hosttwin) -- a test-only twin,
 // never a fallback: the product path is HIP only.
