@@ -10,7 +10,7 @@
 // is rebuilt from the two endpoints (map.h:216-226) -- for the two query predicates without ever
 // forming c (see edge_side and pip_eval_y).
 //
-// RJ_HD lets tests compile these functions for the host (tests/hosttwin) -- a test-only twin,
+// RJ_HD lets tests compile these functions for the host (tests/hosttwin/twin.cc) -- a test-only twin,
 // never a fallback: the product path is HIP only.
 #pragma once
 #include <stdint.h>

@@ -1,0 +1,36 @@
+// Test-only host build of the DEVICE predicate source (rayjoin_amd/csrc/rj_predicates.h): lets the
+// CPU test suite check the exact functions the HIP kernels inline against the reference's golden
+// vectors and the oracle.  Never linked into the product; the product path is HIP only.
+#include <cstdint>
+
+#include "rj_predicates.h"
+
+using namespace rj;
+
+extern "C" {
+
+int twin_lsi_test(const int64_t* s1, const int64_t* s2) {
+  const Seg a = {s1[0], s1[1], s1[2], s1[3]}, b = {s2[0], s2[1], s2[2], s2[3]};
+  return lsi_test(a, b) ? 1 : 0;
+}
+
+// out[0..1] = the narrowing store of the intersection point (lsi.h:107-143), valid when the test is true
+void twin_lsi_stored(const int64_t* s1, const int64_t* s2, int64_t* out) {
+  const Seg a = {s1[0], s1[1], s1[2], s1[3]}, b = {s2[0], s2[1], s2[2], s2[3]};
+  Rat x, y;
+  lsi_point(a, make_eqn(a), b, make_eqn(b), &x, &y);
+  out[0] = (int64_t) rat_to_double(x);
+  out[1] = (int64_t) rat_to_double(y);
+}
+
+// returns 1 when the edge is a candidate; *yy = xsect_y, *slope = (double) a / (double) b
+int twin_pip_eval(const int64_t* s, int64_t px, int64_t py, int query_map_id, double* yy, double* slope) {
+  const Seg e = {s[0], s[1], s[2], s[3]};
+  *slope = pip_slope(e);
+  return pip_eval_y(e, px, py, query_map_id, yy) ? 1 : 0;
+}
+
+int twin_pip_better(double yy, double slope, uint32_t eid, double byy, double bslope, uint32_t beid, int q) {
+  return pip_better(yy, slope, eid, byy, bslope, beid, q) ? 1 : 0;
+}
+}

@@ -1,0 +1,82 @@
+"""The device predicate source (rayjoin_amd/csrc/rj_predicates.h) compiled for the host -- test
+only -- against the reference's golden vectors and the oracle: the sign-only intersect test
+(edge_side), the intersection point, and the two-product PIP numerator must be the reference's
+functions, not merely agree with them on the maps the GPU tests happen to use."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "hosttwin", "twin.cc")
+OUT = os.path.join(ROOT, "tests", "hosttwin", "_build", "libtwin.so")
+
+
+@pytest.fixture(scope="module")
+def twin():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    hdr = os.path.join(ROOT, "rayjoin_amd", "csrc", "rj_predicates.h")
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fwrapv",
+                               "-I", os.path.dirname(hdr), "-o", OUT, SRC])
+    L = C.CDLL(OUT)
+    i64p = C.POINTER(C.c_int64)
+    L.twin_lsi_test.argtypes = [i64p, i64p]
+    L.twin_lsi_stored.argtypes = [i64p, i64p, i64p]
+    L.twin_pip_eval.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.twin_pip_better.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_uint32, C.c_int]
+    return L
+
+
+def _p(a):
+    return np.ascontiguousarray(a, dtype=np.int64).ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def test_device_lsi_predicate_on_reference_golden_pairs(twin):
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "lsi_ref_vectors.json")))
+    out = np.zeros(2, dtype=np.int64)
+    n_hit = 0
+    for rec in gold["pairs"]:
+        s1, s2 = np.array(rec["s1"], dtype=np.int64), np.array(rec["s2"], dtype=np.int64)
+        assert twin.twin_lsi_test(_p(s1), _p(s2)) == rec["hit"], rec
+        if rec["hit"]:
+            twin.twin_lsi_stored(_p(s1), _p(s2), _p(out))
+            assert out.tolist() == rec["stored"], rec
+            n_hit += 1
+    assert n_hit > 100
+
+
+@pytest.mark.parametrize("span,extreme", [(5, False), (40, False), (7, True), (1 << 44, False)])
+def test_device_predicates_fuzz_against_oracle(twin, oracle, span, extreme):
+    rng = np.random.default_rng(span % 1000 + extreme)
+    off = (1 << 46) - span - 1 if extreme else 0
+    segs = rng.integers(-span, span + 1, size=(4000, 4), dtype=np.int64) + off
+    for k in range(0, len(segs) - 1, 2):
+        s1, s2 = segs[k], segs[k + 1]
+        if (s1[0] == s1[2] and s1[1] == s1[3]) or (s2[0] == s2[2] and s2[1] == s2[3]):
+            continue  # zero-length edges cannot come out of a CDB file (planar_graph.h:100-105)
+        assert twin.twin_lsi_test(_p(s1), _p(s2)) == oracle.intersect_test(s1.tolist(), s2.tolist())
+    yy, sl = C.c_double(), C.c_double()
+    pts = rng.integers(-span, span + 1, size=(2000, 2), dtype=np.int64) + off
+    for k in range(2000):
+        s = segs[k]
+        if s[0] == s[2]:
+            continue  # vertical: never a candidate (and its slope is never asked for)
+        for q in (0, 1):
+            got = twin.twin_pip_eval(_p(s), int(pts[k, 0]), int(pts[k, 1]), q, C.byref(yy), C.byref(sl))
+            want, wyy = oracle.pip_single(s.tolist(), pts[k].tolist(), q)
+            assert got == want, (s, pts[k], q)
+            if got:
+                assert yy.value == wyy  # bit-equal doubles
+
+
+def test_device_pip_total_order(twin):
+    # pip.h:73-95 as a total order: lower y wins; ties: slope rule by query map id, then eid
+    assert twin.twin_pip_better(1.0, 0.0, 5, 2.0, 0.0, 1, 1) == 1
+    assert twin.twin_pip_better(2.0, 0.0, 5, 1.0, 0.0, 1, 0) == 0
+    assert twin.twin_pip_better(1.0, 2.0, 5, 1.0, 1.0, 1, 1) == 1 and twin.twin_pip_better(1.0, 2.0, 5, 1.0, 1.0, 1, 0) == 0
+    assert twin.twin_pip_better(1.0, 1.0, 5, 1.0, 1.0, 9, 1) == 1 and twin.twin_pip_better(1.0, 1.0, 5, 1.0, 1.0, 9, 0) == 0
+    assert twin.twin_pip_better(1.0, 1.0, 9, 1.0, 1.0, 5, 0) == 1
