@@ -176,6 +176,29 @@ RJ_HD void lsi_point(const Seg& s1, const Eqn& e1, const Seg& s2, const Eqn& e2,
 }
 
 // ---- PIP ------------------------------------------------------------------------------
+// (double) of a 128-bit integer, round-to-nearest-even like the compiler's conversion (what the
+// reference's `(double) int128` is), but through the top 64 bits + a sticky bit instead of the
+// generic 128-bit expansion: the u64 -> double conversion then does the one rounding (bit 0 only
+// decides exact ties, it is far below the 53 kept bits) and the scaling by a power of two is exact.
+// About 40 VALU instructions less per PIP evaluation on gfx950; checked bit for bit against the
+// compiler's conversion by tests/test_device_predicates_on_host.py.
+RJ_HD double i128_to_double(i128 v) {
+  const bool neg = v < 0;
+  const u128 m = neg ? (u128) 0 - (u128) v : (u128) v;
+  const uint64_t hi = (uint64_t) (m >> 64), lo = (uint64_t) m;
+  double d;
+  if (hi == 0) {
+    d = (double) lo;
+  } else {
+    const int sh = 64 - __builtin_clzll(hi);  // bits of hi in use: 1..64
+    uint64_t top = sh == 64 ? hi : (hi << (64 - sh)) | (lo >> sh);
+    const uint64_t rest = sh == 64 ? lo : lo << (64 - sh);
+    top |= rest != 0;
+    d = __builtin_ldexp((double) top, sh);
+  }
+  return neg ? -d : d;
+}
+
 // One (point, base edge) evaluation, pip.h:36-71.  Returns false when the edge is rejected
 // outright (x range / point above edge); otherwise *yy = xsect_y.
 // The reference divides double(-a px - c) by double(b) with (a, b, c) normalised to b >= 0.
@@ -190,7 +213,7 @@ RJ_HD bool pip_eval_y(const Seg& s, int64_t px, int64_t py, int query_map_id, do
   if (px < x_min || px > x_max || px == (query_map_id == 0 ? x_min : x_max)) return false;
   const int64_t a = s.y1 - s.y2, b = s.x2 - s.x1;
   const i128 num = (i128) a * (s.x1 - px) + (i128) b * s.y1;
-  const double xsect_y = (double) num / (double) b;
+  const double xsect_y = i128_to_double(num) / (double) b;
   double diff_y = (double) py - xsect_y;
   if (diff_y == 0) {
     const int64_t an = b < 0 ? -a : a, bn = b < 0 ? -b : b;

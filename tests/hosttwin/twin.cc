@@ -30,6 +30,13 @@ int twin_pip_eval(const int64_t* s, int64_t px, int64_t py, int query_map_id, do
   return pip_eval_y(e, px, py, query_map_id, yy) ? 1 : 0;
 }
 
+// the custom 128-bit -> double conversion next to the compiler's
+void twin_i128_to_double(int64_t hi, uint64_t lo, double* custom, double* compiler) {
+  const i128 v = (i128) (((u128) (uint64_t) hi << 64) | lo);
+  *custom = i128_to_double(v);
+  *compiler = (double) v;
+}
+
 int twin_pip_better(double yy, double slope, uint32_t eid, double byy, double bslope, uint32_t beid, int q) {
   return pip_better(yy, slope, eid, byy, bslope, beid, q) ? 1 : 0;
 }

@@ -27,6 +27,7 @@ def twin():
     L.twin_lsi_test.argtypes = [i64p, i64p]
     L.twin_lsi_stored.argtypes = [i64p, i64p, i64p]
     L.twin_pip_eval.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.twin_i128_to_double.argtypes = [C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.twin_pip_better.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_uint32, C.c_int]
     return L
 
@@ -80,3 +81,28 @@ def test_device_pip_total_order(twin):
     assert twin.twin_pip_better(1.0, 2.0, 5, 1.0, 1.0, 1, 1) == 1 and twin.twin_pip_better(1.0, 2.0, 5, 1.0, 1.0, 1, 0) == 0
     assert twin.twin_pip_better(1.0, 1.0, 5, 1.0, 1.0, 9, 1) == 1 and twin.twin_pip_better(1.0, 1.0, 5, 1.0, 1.0, 9, 0) == 0
     assert twin.twin_pip_better(1.0, 1.0, 9, 1.0, 1.0, 5, 0) == 1
+
+
+def test_custom_int128_to_double_is_the_compilers(twin):
+    """i128_to_double (top 64 bits + sticky) == (double)(__int128), bit for bit: random magnitudes
+    of every width up to 127 bits, exact ties at the rounding position, all-ones patterns."""
+    rng = np.random.default_rng(12)
+    a, b = C.c_double(), C.c_double()
+    vals = []
+    for bits in range(1, 128):
+        for _ in range(40):
+            vals.append(int(rng.integers(0, 1 << 62)) << max(0, bits - 62) | int(rng.integers(0, 1 << 62)) if bits > 62
+                        else int(rng.integers(0, 1 << bits)))
+        top = 1 << (bits - 1)
+        vals += [top, top - 1, top + 1, (1 << bits) - 1]
+        if bits > 54:  # exact half-way cases and their neighbours at the 53-bit rounding position
+            half = 1 << (bits - 54)
+            for k in (1, 2, 3):
+                base = top + (k << (bits - 53))
+                vals += [base + half, base + half - 1, base + half + 1]
+    for v in vals:
+        for sgn in (1, -1):
+            w = (sgn * v) & ((1 << 128) - 1)
+            hi = (w >> 64) - (1 << 64) if (w >> 64) >= (1 << 63) else (w >> 64)
+            twin.twin_i128_to_double(hi, w & ((1 << 64) - 1), C.byref(a), C.byref(b))
+            assert a.value == b.value and np.signbit(a.value) == np.signbit(b.value), (sgn * v, a.value, b.value)
