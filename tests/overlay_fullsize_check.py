@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Time the overlay stages (polyover_exec's phases, run_overlay.cu:143-228) through the C ABI at
-full size (the bit-exact comparison with the oracle pipeline at this size lives in
-tests/overlay_fullsize_check.py).  GPU only."""
+"""Overlay stages through the C ABI at FULL size, checked bit for bit against the oracle pipeline
+(test infrastructure: run as a child process by tests/test_gpu_fullsize.py so that its 30 M-segment
+maps are freed before the next test)."""
 import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,4 +33,20 @@ xs = [h.alloc(48 * max(1, n)) for _ in range(2)]
 timed("compute_output_polygons", lambda: [h.overlay_edge_xsects(im, pairs, n, xs[im]) for im in range(2)])
 out = {"map0_edges": m[0].n_edges, "map1_edges": m[1].n_edges, "intersections": n, "ms": t,
        "total_query_ms": round(sum(v for k, v in t.items() if k != "build_index_both"), 3)}
+if True:
+    from oracle import rjoracle as O
+    O.lib().rjo_set_num_threads(16)
+    om = [O.Map(m[i].pts, m[i].row_index, m[i].left, m[i].right) for i in range(2)]
+    h.sort_pairs(pairs, n)
+    got_pairs = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
+    want_pairs = O.lsi_grid(om[0], om[1], 2048)["eid"]
+    ok = np.array_equal(got_pairs, want_pairs)
+    for im in range(2):
+        want = O.overlay_edge_xsects(om[0], om[1], im, want_pairs, 2048)
+        h.overlay_edge_xsects(im, pairs, n, xs[im])
+        got = xs[im].to_host(_capi.XSECT_DTYPE, n)
+        ok = ok and all(np.array_equal(got[f], want[f]) for f in ("x_num", "y_num", "eid", "mid_point_polygon_id"))
+        we = O.pip_grid(om[1 - im], 1 - im, m[im].pts, 2048)
+        ok = ok and np.array_equal(fc[im].to_host(np.int32), om[1 - im].face_ids(we))
+    out["bit_exact_vs_oracle"] = bool(ok)
 print(json.dumps(out))

@@ -40,11 +40,13 @@ def test_no_gpu_is_a_loud_error_not_a_fallback():
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing under rayjoin_amd/ may reference it."""
-    pkg = os.path.join(ROOT, "rayjoin_amd")
-    for dp, _, fns in os.walk(pkg):
+    """The oracle is test infrastructure: nothing under rayjoin_amd/ (or the diagnostics in tools/)
+    may reference it."""
+    import itertools
+    walks = itertools.chain(os.walk(os.path.join(ROOT, "rayjoin_amd")), os.walk(os.path.join(ROOT, "tools")))
+    for dp, _, fns in walks:
         for fn in fns:
-            if fn.endswith((".py", ".hip", ".h", ".cc", ".cpp")) or fn == "Makefile":
+            if fn.endswith((".py", ".hip", ".h", ".cc", ".cpp", ".sh")) or fn == "Makefile":
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 for needle in ("rjoracle", "rj_oracle", "import oracle", "from oracle", "librj_oracle",
                                "liblsi_ref", "_ref/"):

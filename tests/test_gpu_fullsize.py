@@ -132,14 +132,14 @@ def test_lakes_parks_pip_full_base(oracle):
 def test_uscounty_zipcode_overlay_stages_full_size():
     """BASELINE.json configs[3] (USCounty x Zipcode overlay) at FULL size: IntersectEdge,
     LocateVerticesInOtherMap (both maps) and the per-map ComputeOutputPolygons records, bit-exact
-    against the oracle's -mode=grid pipeline (tools/overlay_probe.py --check does the comparison;
+    against the oracle's -mode=grid pipeline (tests/overlay_fullsize_check.py does the comparison;
     run as a child process so its 30 M-segment maps are freed before the next test)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "overlay_probe.py"), "--check"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "overlay_fullsize_check.py")],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
