@@ -39,7 +39,12 @@ typedef enum {
   RJ_E_HIP = 2,       /* a HIP runtime call failed; see rj_last_error_string */
   RJ_E_OVERFLOW = 3,  /* result queue capacity exceeded; *n_found holds the true count.
                          (The reference only asserts here: src/util/queue.h:37.) */
-  RJ_E_NOMEM = 4
+  RJ_E_NOMEM = 4,
+  RJ_E_INTERNAL = 5   /* a traversal stack of the query kernels overflowed: results incomplete.  The
+                         stacks cover the worst case of every index rj_build_lbvh accepts, so this is
+                         a defect report, not an input error.  (The reference: a fixed 64-entry stack
+                         per thread, unchecked -- deps/lbvh/lbvh/query.cuh:16.)  Reported by the call
+                         that synchronises: rj_lsi_query(_finish), rj_pip_query, rj_sync. */
 } rj_status;
 
 #define RJ_MISS_EID 0xFFFFFFFFu /* static_cast<index_t>(DONTKNOW), src/app/pip_lbvh.h:44 */

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAYJOIN_AMD_LIB") or os.path.join(HERE, "librayjoin_amd.so")  # override: A/B builds
 
-RJ_OK, RJ_E_INVALID, RJ_E_HIP, RJ_E_OVERFLOW, RJ_E_NOMEM = 0, 1, 2, 3, 4
+RJ_OK, RJ_E_INVALID, RJ_E_HIP, RJ_E_OVERFLOW, RJ_E_NOMEM, RJ_E_INTERNAL = 0, 1, 2, 3, 4, 5
 RJ_T_BUILD, RJ_T_LSI_KERNEL, RJ_T_PIP_KERNEL, RJ_T_LSI_POINTS, RJ_T_SORT, RJ_T_ORDER = 0, 1, 2, 3, 4, 5
 MISS_EID = 0xFFFFFFFF
 

@@ -67,9 +67,16 @@ struct rj_handle_s {
   hipStream_t stream = nullptr;
   MapState map[2];
   BvhState bvh[2];
-  unsigned long long* d_counter = nullptr;  // [0] LSI result count; +128 B: 8 scheduler counters, 128 B apart
-  unsigned long long* d_stats = nullptr;    // [4]
-  unsigned long long* h_pinned = nullptr;   // [8] pinned read-back area
+  // d_counter (u64 words): [0] LSI result count; [2],[3] grid build; [4],[5] group-extent estimate;
+  // then three scheduler blocks of 8 counters 128 B apart: LSI, PIP on the main stream, PIP on aux
+  unsigned long long* d_counter = nullptr;
+  unsigned long long* d_stats = nullptr;    // [16]
+  unsigned long long* h_pinned = nullptr;   // [32] pinned read-back area
+  // Traversal-stack fault words, [0] LSI [1] PIP: pinned host memory the kernels write directly
+  // (never in practice: rj_device.h), so every sync point can check them without a copy
+  uint32_t* h_fault = nullptr;
+  uint32_t* d_fault = nullptr;              // the same memory as the device sees it
+  int debug_stack_cap = 1 << 30;            // tests of the fault path only
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
@@ -174,6 +181,20 @@ hipError_t join_aux(rj_handle h) {
 
 uint64_t pad64(uint64_t n) { return (n + 63) / 64 * 64; }
 
+constexpr size_t kSchedBlockWords = 8 * 128 / 8 + 16;            // one scheduler block, in u64 words (+ the fault-pointer line)
+constexpr size_t kSchedZeroBytes = 8 * 128;                      // what is cleared before a launch
+constexpr size_t kSchedLsi = 16, kSchedPipMain = kSchedLsi + kSchedBlockWords, kSchedPipAux = kSchedPipMain + kSchedBlockWords;
+constexpr size_t kCounterBytes = (kSchedPipAux + kSchedBlockWords) * 8;
+
+// after a stream sync: did a traversal stack overflow?  (cannot for an index rj_build_lbvh accepted)
+int check_fault(rj_handle h) {
+  const uint32_t l = h->h_fault[0], p = h->h_fault[1];
+  if (!l && !p) return RJ_OK;
+  h->h_fault[0] = h->h_fault[1] = 0;
+  return fail(h, RJ_E_INTERNAL, "traversal stack overflow in %s%s%s: results are incomplete", l ? "k_lsi" : "",
+              l && p ? " and " : "", p ? "k_pip" : "");
+}
+
 }  // namespace
 
 extern "C" {
@@ -192,9 +213,17 @@ int rj_create(int device_id, rj_handle* out) {
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RJ_E_HIP; }
   h->stream = h->own_stream;
   if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipStreamDestroy(h->own_stream); delete h; return RJ_E_HIP; }
-  bool ok = hipMalloc((void**) &h->d_counter, 128 + 2 * 8 * 128) == hipSuccess &&  // count + LSI scheduler + PIP scheduler
+  bool ok = hipMalloc((void**) &h->d_counter, kCounterBytes) == hipSuccess &&
             hipMalloc((void**) &h->d_stats, 128) == hipSuccess &&
-            hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess;
+            hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess &&
+            hipHostMalloc((void**) &h->h_fault, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**) &h->d_fault, h->h_fault, 0) == hipSuccess;
+  if (ok) {
+    h->h_fault[0] = h->h_fault[1] = 0;
+    ok = hipMemset(h->d_counter, 0, kCounterBytes) == hipSuccess;
+    for (size_t blk : {kSchedLsi, kSchedPipMain, kSchedPipAux})  // behind each block's counters: where its kernel reports a fault
+      ok = ok && hipMemcpy((char*) (h->d_counter + blk) + kSchedFaultPtrWord * 4, &h->d_fault, sizeof(h->d_fault), hipMemcpyHostToDevice) == hipSuccess;
+  }
   for (int t = 0; ok && t < kNumTimers; t++)
     ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
   if (!ok) { delete h; return RJ_E_HIP; }
@@ -208,7 +237,7 @@ int rj_destroy(rj_handle h) {
   (void) hipStreamSynchronize(h->stream);
   (void) hipStreamSynchronize(h->aux_stream);
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
-  (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned);
+  (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
   (void) hipFree(h->arena);
@@ -231,7 +260,7 @@ int rj_sync(rj_handle h) {
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   RJ_HIP(h, join_aux(h));
-  return RJ_OK;
+  return check_fault(h);
 }
 
 const char* rj_last_error_string(rj_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -261,6 +290,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "chunk_groups")) {
     if (value < 1 || value > 4096) return fail(h, RJ_E_INVALID, "chunk_groups out of range");
     h->chunk_groups = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "debug_stack_cap")) {  // tests only (honoured by the "stats" kernels): shrink the traversal stacks to exercise the fault path
+    if (value < 1) return fail(h, RJ_E_INVALID, "debug_stack_cap must be positive");
+    h->debug_stack_cap = value > (1 << 30) ? (1 << 30) : (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "max_blocks")) {
@@ -293,24 +327,31 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   free_grid(h->grid[map_id]);
   h->coh[0][map_id].valid = h->coh[1][map_id].valid = false;
   m.np = np; m.nc = nc; m.ne = np - nc;
-  if (int r = dev_alloc(h, &m.pts, 2 * np + 2)) return r;
-  if (int r = dev_alloc(h, &m.seg, m.ne)) return r;
-  if (int r = dev_alloc(h, &m.edge_chain, m.ne)) return r;
-  if (int r = dev_alloc(h, &m.left, nc)) return r;
-  if (int r = dev_alloc(h, &m.right, nc)) return r;
   std::vector<uint32_t> eb(nc + 1), l32(nc), r32(nc);
   for (uint64_t c = 0; c <= nc; c++) eb[c] = nc ? (uint32_t) (row_index[c] - c) : 0;
   for (uint64_t c = 0; c < nc; c++) { l32[c] = (uint32_t) left[c]; r32[c] = (uint32_t) right[c]; }  // map.h:45
   uint32_t* d_eb = nullptr;
-  if (int r = dev_alloc(h, &d_eb, nc + 1)) return r;
+  int rc = RJ_OK;
+  if (!rc) rc = dev_alloc(h, &m.pts, 2 * np + 2);
+  if (!rc) rc = dev_alloc(h, &m.seg, m.ne);
+  if (!rc) rc = dev_alloc(h, &m.edge_chain, m.ne);
+  if (!rc) rc = dev_alloc(h, &m.left, nc);
+  if (!rc) rc = dev_alloc(h, &m.right, nc);
+  if (!rc) rc = dev_alloc(h, &d_eb, nc + 1);
   hipError_t e = hipSuccess;
-  if (np) e = hipMemcpyAsync(m.pts, xy, 16 * np, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess && nc) e = hipMemcpyAsync(d_eb, eb.data(), 4 * (nc + 1), hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess && nc) e = hipMemcpyAsync(m.left, l32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess && nc) e = hipMemcpyAsync(m.right, r32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
-  if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, d_eb, (uint32_t) nc, m.ne, m.seg, m.edge_chain);
-  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  if (!rc) {
+    if (np) e = hipMemcpyAsync(m.pts, xy, 16 * np, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(d_eb, eb.data(), 4 * (nc + 1), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(m.left, l32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(m.right, r32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, d_eb, (uint32_t) nc, m.ne, m.seg, m.edge_chain);
+    // whatever was enqueued reads the host vectors and d_eb: drain the stream before they go away
+    const hipError_t es = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = es;
+  }
   (void) hipFree(d_eb);
+  if (rc || e != hipSuccess) free_map(m);  // no half-uploaded map
+  if (rc) return rc;
   RJ_HIP(h, e);
   m.present = true;
   return RJ_OK;
@@ -445,9 +486,9 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
     if (cc && cc->valid && cc->begin == key_begin && cc->n == n) {
       incoherent = cc->incoherent;  // same immutable range as last time: no estimate, no sync
     } else {
-      RJ_HIP(h, hipMemsetAsync(h->d_stats + 14, 0, 16, h->stream));
-      RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_stats + 14));
-      RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_stats + 14, 16, hipMemcpyDeviceToHost, h->stream));
+      RJ_HIP(h, hipMemsetAsync(h->d_counter + 4, 0, 16, h->stream));
+      RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_counter + 4));
+      RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_counter + 4, 16, hipMemcpyDeviceToHost, h->stream));
       RJ_HIP(h, hipStreamSynchronize(h->stream));
       const unsigned long long sum = h->h_pinned[20], groups = h->h_pinned[21];
       incoherent = groups != 0 && sum / groups > kIncoherentExtent;
@@ -475,7 +516,8 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (qb > qe || qe > h->map[query_map_id].ne) return fail(h, RJ_E_INVALID, "rj_lsi_query: bad query eid range");
   if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query: null output");
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 128 + 8 * 128, h->stream));  // Queue::Clear (queue.h:125-129) + scheduler
+  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear (queue.h:125-129)
+  RJ_HIP(h, hipMemsetAsync(h->d_counter + kSchedLsi, 0, kSchedZeroBytes, h->stream));
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   const uint32_t* order = nullptr;
   if (int r = maybe_order_queries(h, false, nullptr, h->map[query_map_id].seg, qb, qe - qb, &order, query_map_id, qb)) return r;
@@ -487,9 +529,10 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.base_is_map0 = base_map_id == 0;
   a.out = pairs_dev; a.cap = capacity;
   a.counter = h->d_counter;
-  a.work_counter = (unsigned int*) (h->d_counter + 16);
+  a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi);
   a.chunk_groups = (uint32_t) h->chunk_groups;
   a.group_lanes = (uint32_t) h->group_lanes;
+  a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_LSI_KERNEL);
   if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, h->max_blocks));
@@ -512,6 +555,7 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   uint64_t n = h->h_pinned[0];
   if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
   if (n_found) *n_found = n;
+  if (int r = check_fault(h)) return r;
   if (n > capacity)
     return fail(h, RJ_E_OVERFLOW, "intersection queue overflow: %llu found, capacity %llu",
                 (unsigned long long) n, (unsigned long long) capacity);
@@ -598,8 +642,10 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   const bool small = n < (uint64_t) 6000000;
   const bool aux = (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && small)) && !order && !h->stats_on;
   hipStream_t st = aux ? h->aux_stream : h->stream;
-  unsigned long long* sched = h->d_counter + 16 + 128;  // PIP's own scheduler counters
-  RJ_HIP(h, hipMemsetAsync(sched, 0, 8 * 128, st));
+  // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
+  // in flight together (calls on ONE stream are ordered by the stream)
+  unsigned long long* sched = h->d_counter + (aux ? kSchedPipAux : kSchedPipMain);
+  RJ_HIP(h, hipMemsetAsync(sched, 0, kSchedZeroBytes, st));
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.base = map_view(h->map[base_map_id]);
@@ -610,6 +656,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.work_counter = (unsigned int*) sched;
   a.chunk_groups = (uint32_t) h->chunk_groups;
   a.group_lanes = (uint32_t) h->group_lanes;
+  a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_PIP_KERNEL, st);
   if (n) RJ_HIP(h, launch_pip(st, a, h->stats_on, h->max_blocks));
@@ -626,7 +673,7 @@ int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* 
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   RJ_HIP(h, join_aux(h));
   if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
-  return RJ_OK;
+  return check_fault(h);
 }
 
 

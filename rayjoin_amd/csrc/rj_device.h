@@ -20,8 +20,25 @@
 namespace rj {
 
 constexpr int kWave = 64;
-constexpr int kMaxLevels = 6;          // levels 1..5 suffice for 2^32 segments (64^5 = 2^30 leaves blocks)
-constexpr int kStackEntries = 64 * 5 + 64;
+constexpr int kMaxLevels = 6;          // levels 1..5 suffice for 2^32 segments (64^5 = 2^30 leaf blocks)
+constexpr int kMaxTop = kMaxLevels - 1;  // highest level a tree accepted by rj_build_lbvh can have
+// Traversal stacks (per wave, LDS).  Worst case = every child of every node overlaps the query
+// group (one domain-spanning query is enough), depth-first from <= 64 top-level entries:
+//   * popping ONE entry and pushing its <= 64 children grows the stack by <= 63 per level
+//     descended: 64 + 63 (top - 1) entries (k_pip);
+//   * popping TWO entries per step (k_lsi keeps two node loads in flight) grows it by <= 126 per
+//     step, and by induction over the level of the entries on top (a batch of pushed children is
+//     consumed completely before anything below it is touched) by <= 126 (top - 1) in all:
+//     64 + 126 (top - 1) entries.
+// Both bounds are checked against a simulation of the stack discipline in
+// tests/test_stack_bounds.py; the kernels still test every push against the capacity and raise
+// the handle's fault word (-> RJ_E_INTERNAL) instead of writing past the stack.
+constexpr int kStackEntries = 64 + 126 * (kMaxTop - 1);  // 568
+constexpr int kPipStack = 64 + 63 * (kMaxTop - 1) + 4;   // 320 (316 needed)
+constexpr uint32_t kFaultLsiStack = 0, kFaultPipStack = 1;  // index of the kernel's word in the handle's fault words
+// A scheduler block = 8 chunk counters 128 B apart (zeroed before every launch) followed by one
+// line that is written once: the device-visible address of the handle's fault words.
+constexpr int kSchedFaultPtrWord = 8 * 32;  // in 32-bit words from the block's start
 constexpr int kPairBuf = 128;          // >= 64 (carry) + 64 (one append step)
 constexpr int kQuantShift = 16;
 constexpr int64_t kCoordOffset = (int64_t) 1 << 46;

@@ -24,6 +24,7 @@ struct LsiArgs {
   unsigned int* work_counter;   // dynamic chunk scheduler (zeroed before every launch)
   uint32_t chunk_groups;        // consecutive groups per chunk
   uint32_t group_lanes;         // queries per wave (0 = choose from the query count)
+  int stack_cap;                // instrumented kernel only: use fewer stack entries (tests of the fault path)
   unsigned long long* stats;    // [4] or nullptr
 };
 
@@ -39,6 +40,7 @@ struct PipArgs {
   unsigned int* work_counter;
   uint32_t chunk_groups;
   uint32_t group_lanes;  // points per wave (0 = choose from the point count)
+  int stack_cap;         // instrumented kernel only: use fewer stack entries (tests of the fault path)
   unsigned long long* stats;
 };
 

@@ -320,6 +320,24 @@ __device__ __forceinline__ bool next_chunk(unsigned int* counters, uint32_t nchu
   return false;
 }
 
+// Every push onto a traversal stack is checked against its capacity (wave-uniform scalars: three
+// scalar instructions).  The capacities cover the worst case of every tree rj_build_lbvh accepts
+// (rj_device.h), so this never fires; if it did, the children are dropped and the handle's fault
+// word -- pinned host memory the device writes directly -- turns the query into RJ_E_INTERNAL
+// instead of a silently corrupted stack (the reference: a fixed 64-entry per-thread stack with no
+// check at all, deps/lbvh/lbvh/query.cuh:16).  The fault word's address sits behind the kernel's
+// scheduler counters (kSchedFaultPtrWord), so the cold path costs the hot loops no register.
+__device__ __noinline__ void raise_fault(unsigned int* work_counter, uint32_t which) {
+  uint32_t* fault = *reinterpret_cast<uint32_t* const*>(work_counter + kSchedFaultPtrWord);
+  // a plain store (idempotent; one word per kernel kind), not an atomic: no PCIe atomics needed
+  __hip_atomic_store(fault + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ bool stack_has_room(int sp, int n, int cap, unsigned int* work_counter, uint32_t which, int lane) {
+  if (sp + n <= cap) return true;
+  if (lane == 0) raise_fault(work_counter, which);
+  return false;
+}
+
 // =============================================================================================
 // LSI: wave-cooperative traversal, LDS stack, ballot-compacted candidate pairs, dense predicate
 // =============================================================================================
@@ -387,6 +405,7 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
   const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
   const bool occ_usable = T.occ[(size_t) kOccDim * kOccRowWords] == 0;  // every base segment was rasterised
+  const int stack_cap = STATS && A.stack_cap < kStackEntries ? A.stack_cap : kStackEntries;  // (lowered only by tests of the fault path, instrumented kernel)
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
   long long tk_node = 0, tk_leaf = 0, tk_head = 0, tk_sched = 0;  // STATS: cycle stamps
@@ -450,6 +469,7 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
     {  // top level: <= 64 nodes, one per lane
       QBox b = T.lvl[T.top][lane];
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
       if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
       sp = __popcll(m);
       wave_lds_fence();
@@ -464,6 +484,8 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
       const long long tk0 = STATS ? clock64() : 0;
       if (lvl > 1) {
         uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+        // (cannot happen for a tree rj_build_lbvh accepted: kStackEntries covers the worst case, rj_device.h)
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
         if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
         sp += __popcll(m);
         if (STATS) st_nodes++;
@@ -654,9 +676,9 @@ __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, u
 //   * the kernel is VALU-issue bound: the exact test computes two 128-bit
 //     products, and the slope only on ties.
 // =============================================================================================
-constexpr int kPipList = 8;     // candidate slots per lane between two exact-evaluation rounds
+constexpr int kPipList = 6;     // candidate slots per lane between two exact-evaluation rounds
 constexpr int kPipRefineAbove = 16;  // per-lane check at push time only when more children than this pass the group test
-constexpr int kPipStack = 64 * 4;  // >= 63 * (levels - 1) + 64 entries for <= 4 expanded levels
+// (kPipStack: rj_device.h -- 16-byte entries; with the lists, 6656 B per wave = 6 blocks per CU)
 
 // A stack entry carries the node's y0 and x-range, so a stale entry (every lane under it has since
 // found something lower) is dropped at pop time without touching memory.
@@ -675,6 +697,7 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
   const uint64_t ngroups = (A.n + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
+  const int stack_cap = STATS && A.stack_cap < kPipStack ? A.stack_cap : kPipStack;  // (lowered only by tests of the fault path, instrumented kernel)
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
   unsigned long long st_stale = 0, st_leaf_nocand = 0, st_leaf_lanes = 0;
   long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_rounds = 0, tk_sched = 0, tk_head = 0, tk_tail = 0;  // STATS: cycle stamps
@@ -773,6 +796,7 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
     {
       QBox b = T.lvl[T.top][lane];
       uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
+      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
       const int n = __popcll(m);
       // reversed so that lane 0's child (lowest Morton = lowest y half) pops first
       if ((m >> lane) & 1)
@@ -800,6 +824,7 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
         const long long tk0 = STATS ? clock64() : 0;
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
         uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
         const int n = __popcll(m);
         if ((m >> lane) & 1)
           L.stack[sp + n - 1 - rank_below(m)] =
