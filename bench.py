@@ -2,7 +2,8 @@
 """bench.py -- LSI + PIP query throughput of the MI355X-native path (BASELINE.json metric).
 
 A step = one LSI Query (all query-map segments against the indexed base map: queue clear,
-kernel, count read-back, sync -- exactly what the reference times, src/run_query.cu:297-303)
+traversal + predicate kernel, the 48-byte Intersection record of every hit, count read-back, sync
+-- what the reference times, src/run_query.cu:297-303 around src/app/lsi_lbvh.h:27-98)
 followed by one PIP Query (every vertex of the query map, src/run_query.cu:346,441-457).
 Workload (N=1): BASELINE.json configs[1], USCounty (base, 7.1 M segments) |><| BlockGroup
 (query, 28.8 M segments), as synthetic stand-ins of those sizes (the real files are
@@ -150,6 +151,7 @@ def main():
     cap = int(args.xsect_factor * (n_r + n_s))  # run_query.cu:226-228
     closest = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
     faces = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
+    xsects = torch.empty((cap, 6), dtype=torch.int64, device=dev)  # dev::Intersection<int64_t>, 48 B each
     if world > 1:
         # count + pairs leave in one all-gather on a second stream, overlapped with the PIP kernel
         ex = rjd.PairExchange(cap, dev, slot=max(4096, int(0.02 * cap)))
@@ -158,12 +160,13 @@ def main():
     else:
         pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
 
-    lsi_ms, pip_ms = [], []
+    lsi_ms, pip_ms, pts_ms = [], [], []
     state = {}
 
     def step(record):
-        # both kernels are enqueued back to back; the step's single host sync is the count read-back
+        # everything is enqueued back to back; the step's single host sync is the count read-back
         h.lsi_query_async(0, 1, e0, e1, cap, pairs)
+        h.lsi_points_async(pairs, cap, xsects)  # the records of this rank's hits (count read on the device)
         if world > 1:
             ex.begin(h)
         h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
@@ -176,6 +179,7 @@ def main():
         if record:
             lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
             pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
+            pts_ms.append(h.last_ms(_capi.RJ_T_LSI_POINTS))
         if world > 1 and args.gather_pip:  # optional: all-gather of the PIP result queues
             state["ids_all"] = rjd.allgather_point_results(closest, p1 - p0, max_pts)
         state["n"] = n
@@ -204,6 +208,29 @@ def main():
         n_x = state["n"]
     ms_per_step = elapsed * 1e3 / args.steps
 
+    # order-independent digest of the step's results, summed over ranks (untimed): lets a test compare
+    # an N-rank run with the single-GPU run of the same workload without shipping the results
+    def digest():
+        n = state["n"]
+        pr = pairs[:n].to(torch.int64) & 0xFFFFFFFF
+        xs = xsects[:n]
+        pc = closest[:p1 - p0].to(torch.int64) & 0xFFFFFFFF
+        hit = pc != 0xFFFFFFFF
+        v = torch.stack([
+            ((pr[:, 0] * 2654435761 + pr[:, 1] * 40503) % 2147483647).sum(),
+            ((xs[:, 0] % 1000003) + (xs[:, 2] % 1000033)).sum(),
+            hit.sum(), (pc[hit] % 2147483647).sum(), faces[:p1 - p0].to(torch.int64).sum()]).to(torch.int64)
+        if world > 1:
+            if dist.get_backend() == "gloo":
+                c = v.cpu()
+                dist.all_reduce(c)
+                v = c
+            else:
+                dist.all_reduce(v)
+        names = ("pairs", "points_xy", "pip_hits", "pip_eids", "pip_faces")
+        return {k: int(x) for k, x in zip(names, v.tolist())}
+    result_digest = digest()
+
     # phase split (synchronous calls, wall clock), one extra untimed pass
     t0 = time.perf_counter(); h.lsi_query(0, 1, e0, e1, cap, pairs); t_lsi_wall = time.perf_counter() - t0
     t0 = time.perf_counter(); h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); t_pip_wall = time.perf_counter() - t0
@@ -218,16 +245,34 @@ def main():
         n_s_loc, n_p_loc = e1 - e0, p1 - p0
         b_lsi = 32 * n_s_loc + 32 * n_r + 8 * state["n"]
         b_pip = 16 * n_p_loc + 32 * n_r + 4 * n_p_loc + 4 * n_p_loc  # + face ids
-        traffic = {}
+        # PMC evidence (tools/profile_run.sh + tools/pmc_summary.py): quoted only for the headline
+        # workload and only while it was measured on exactly these kernel sources
+        traffic, sq, prof_note = {}, {}, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and args.scale == 1.0:
-            traffic = json.load(open(tp))
+        headline = world == 1 and args.scale == 1.0 and not args.emulate_shard and (args.base, args.query) == ("USCounty", "BlockGroup")
+        if os.path.exists(tp) and headline:
+            doc = json.load(open(tp))
+            if doc.get("kernel_source_hash") == _capi.kernel_source_hash():
+                traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_*" % doc.get("tag")
+            else:
+                prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
         roof = {}
         for name, b, ms, kern in (("lsi", b_lsi, lsi_k, "k_lsi"), ("pip", b_pip, pip_k, "k_pip")):
             ach = b / (ms * 1e-3) / 1e9
             roof[name] = {"bound": "hbm", "kernel": kern, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(kern),
-                          "algorithmic_bytes": b, "kernel_ms": round(ms, 4)}
+                          "algorithmic_bytes": b, "kernel_ms": round(ms, 4), "pmc_source": prof_note}
+            c = sq.get(kern, {})
+            if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
+                # busy quad-cycles of the VALUs over the quad-cycles 1024 SIMDs have while the kernel runs
+                # (GRBM_GUI_ACTIVE sums the 8 XCDs): what actually limits a kernel whose HBM traffic is
+                # already the algorithmic minimum
+                avail = c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
+                roof[name]["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] / avail, 3)
+                if c.get("SQ_ACTIVE_INST_SCA"):
+                    roof[name]["salu_busy_frac"] = round(c["SQ_ACTIVE_INST_SCA"] / (c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 256.0), 3)
+                if roof[name]["valu_busy_frac"] > 0.6:
+                    roof[name]["limiter"] = "valu-issue"
         dom = "lsi" if lsi_k >= pip_k else "pip"
         out = {
             "metric": "LSI+PIP query throughput, %s |><| %s" % (args.base, args.query),
@@ -245,6 +290,7 @@ def main():
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
             "pip_mpoints_per_s": round(n_p / max(t_pip_wall, 1e-9) / 1e6, 2) if world == 1 else None,
+            "lsi_points_ms": round(float(np.mean(pts_ms)), 4), "result_digest": result_digest,
             "intersections": n_x, "build_index_ms": round(build_ms, 3),
             "host_ms": {"generate": round(t_gen * 1e3, 1), "upload_and_segment_build": round(t_upload * 1e3, 1)},
             "roofline": roof[dom], "roofline_other": roof["pip" if dom == "lsi" else "lsi"],

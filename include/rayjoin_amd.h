@@ -115,6 +115,12 @@ int rj_lsi_count_to(rj_handle h, uint64_t* n_found_dev);
  * Intersection<int64_t> (src/algo/lsi.h:107-143, src/app/lsi_lbvh.h:71-78).
  * pairs_dev: n (eid map 0, eid map 1) pairs; out_dev: n rj_xsect records. */
 int rj_lsi_points(rj_handle h, const uint32_t* pairs_dev, uint64_t n, rj_xsect* out_dev);
+/* The same for the result of the last rj_lsi_query_async, enqueued behind it on the handle's stream:
+ * the number of records is read on the device from the queue's counter (min(count, capacity)), so
+ * that "Query" leaves complete 48-byte records like the reference's (src/app/lsi_lbvh.h:71-78)
+ * without a host round trip between the two kernels.  pairs_dev / capacity: what the query was given;
+ * out_dev[capacity].  Complete after rj_lsi_query_finish / rj_sync. */
+int rj_lsi_points_async(rj_handle h, const uint32_t* pairs_dev, uint64_t capacity, rj_xsect* out_dev);
 
 /* sort n pairs in place by (eid0, eid1) -- the canonical order of the reference's checker
  * (src/run_overlay.cu:38-52) */

@@ -38,6 +38,7 @@ SYMBOLS = {
     "rj_lsi_query_finish": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "rj_lsi_count_to": (_int, [_vp, _vp]),
     "rj_lsi_points": (_int, [_vp, _vp, _u64, _vp]),
+    "rj_lsi_points_async": (_int, [_vp, _vp, _u64, _vp]),
     "rj_sort_pairs": (_int, [_vp, _vp, _u64]),
     "rj_comm_unique_id": (_int, [_vp]),
     "rj_comm_init": (_int, [_vp, _int, _int, _vp]),
@@ -58,6 +59,17 @@ SYMBOLS = {
     "rj_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "rj_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
 }
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) of the HIP sources the query kernels are built from: profile artefacts
+    (profiles/traffic.json) carry it, and bench.py only quotes them for the sources they measured."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("rj_kernels.hip", "rj_kernels.h", "rj_device.h", "rj_predicates.h"):
+        with open(os.path.join(HERE, "csrc", name), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
 
 
 class RayJoinError(RuntimeError):
@@ -172,6 +184,7 @@ class Handle:
 
     def set_stream(self, stream_ptr):
         self._check(self.L.rj_set_stream(self.h, stream_ptr))
+        self._stream_ptr = stream_ptr  # (dist.PairExchange checks that its event and the kernels share a stream)
 
     def sync(self):
         self._check(self.L.rj_sync(self.h))
@@ -249,6 +262,10 @@ class Handle:
 
     def lsi_points(self, pairs_dev, n, out_dev):
         self._check(self.L.rj_lsi_points(self.h, _ptr(pairs_dev), n, _ptr(out_dev)))
+
+    def lsi_points_async(self, pairs_dev, capacity, out_dev):
+        """records of the last lsi_query_async, behind it on the stream (count read on the device)"""
+        self._check(self.L.rj_lsi_points_async(self.h, _ptr(pairs_dev), capacity, _ptr(out_dev)))
 
     @staticmethod
     def comm_unique_id():

@@ -583,9 +583,20 @@ int rj_lsi_points(rj_handle h, const uint32_t* pairs_dev, uint64_t n, rj_xsect* 
   if (n && (!pairs_dev || !out_dev)) return fail(h, RJ_E_INVALID, "rj_lsi_points: null buffer");
   if (int r = set_device(h)) return r;
   tic(h, RJ_T_LSI_POINTS);
-  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, (XsectRec*) out_dev));
+  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, nullptr, (XsectRec*) out_dev));
   toc(h, RJ_T_LSI_POINTS);
   RJ_HIP(h, hipStreamSynchronize(h->stream));
+  return RJ_OK;
+}
+
+int rj_lsi_points_async(rj_handle h, const uint32_t* pairs_dev, uint64_t capacity, rj_xsect* out_dev) {
+  RJ_CHECK_H(h);
+  if (!h->map[0].present || !h->map[1].present) return fail(h, RJ_E_INVALID, "rj_lsi_points_async: both maps must be uploaded");
+  if (capacity && (!pairs_dev || !out_dev)) return fail(h, RJ_E_INVALID, "rj_lsi_points_async: null buffer");
+  if (int r = set_device(h)) return r;
+  tic(h, RJ_T_LSI_POINTS);
+  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, capacity, h->d_counter, (XsectRec*) out_dev));
+  toc(h, RJ_T_LSI_POINTS);
   return RJ_OK;
 }
 
@@ -921,7 +932,7 @@ int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint6
   hipError_t e = hipSuccess;
   do {
     // 1. the 48-byte records  2. order by (eid[im], eid[1-im])  3. per-edge order by distance, mid-points
-    if ((e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, tmp)) != hipSuccess) break;
+    if ((e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, nullptr, tmp)) != hipSuccess) break;
     if ((e = launch_xsect_keys(h->stream, tmp, n, im, kin, vin)) != hipSuccess) break;
     if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, kin, kout, vin, vout, n)) != hipSuccess) break;
     if ((e = launch_xsect_gather(h->stream, tmp, vout, n, (XsectRec*) xsects_dev)) != hipSuccess) break;

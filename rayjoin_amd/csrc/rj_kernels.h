@@ -101,7 +101,7 @@ hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, 
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                              uint64_t n, MortonKey* keys, uint32_t* vals);
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
-                             uint64_t n, XsectRec* out);
+                             uint64_t n, const unsigned long long* n_dev, XsectRec* out);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
 
 }  // namespace rj

@@ -561,10 +561,17 @@ __global__ __launch_bounds__(256, 6) void k_lsi(LsiArgs A) {
 // =============================================================================================
 // LSI intersection points (per hit only): rational point, clamp, narrowing store
 // =============================================================================================
+// n_dev (nullable): the result count as the LSI kernel left it on the device -- the records of a
+// query are then produced on the stream with no host round trip in between (min(*n_dev, n) pairs).
 __global__ __launch_bounds__(256) void k_lsi_points(const Seg* __restrict__ seg0,
                                                     const Seg* __restrict__ seg1,
                                                     const uint32_t* __restrict__ pairs, uint64_t n,
+                                                    const unsigned long long* __restrict__ n_dev,
                                                     XsectRec* __restrict__ out) {
+  if (n_dev) {
+    const unsigned long long found = *n_dev;
+    n = found < n ? found : n;
+  }
   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n;
        i += (uint64_t) gridDim.x * blockDim.x) {
     uint32_t e0 = pairs[2 * i], e1 = pairs[2 * i + 1];
@@ -1059,9 +1066,11 @@ hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, co
 }
 
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
-                             uint64_t n, XsectRec* out) {
+                             uint64_t n, const unsigned long long* n_dev, XsectRec* out) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_lsi_points, dim3(grid_for(n, 256, 4096)), dim3(256), 0, st, seg0, seg1, pairs, n, out);
+  // with a device-side count the grid is sized for a typical result, the loop is grid-stride anyway
+  const uint64_t expect = n_dev ? (n < (1u << 20) ? n : (1u << 20)) : n;
+  hipLaunchKernelGGL(k_lsi_points, dim3(grid_for(expect, 256, 4096)), dim3(256), 0, st, seg0, seg1, pairs, n, n_dev, out);
   return hipGetLastError();
 }
 

@@ -119,7 +119,16 @@ class PairExchange:
         return out.view(self.world, 2 + 2 * slot)
 
     def begin(self, handle):
-        """after the async LSI launch: stamp the count, then start the exchange behind an event"""
+        """after the async LSI launch: stamp the count, then start the exchange behind an event.
+        The event is recorded on torch's current stream, so the handle must be working on that
+        stream (its default is a private one): `handle.set_stream(torch.cuda.current_stream()
+        .cuda_stream)` before the LSI launch, or the collective could ship an unfinished queue --
+        checked here instead of assumed."""
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device).cuda_stream
+            if getattr(handle, "_stream_ptr", None) != cur:
+                raise RuntimeError("PairExchange: call handle.set_stream(torch.cuda.current_stream().cuda_stream) "
+                                   "before the LSI launch -- the exchange is ordered behind torch's current stream")
         handle.lsi_count_to(self.send)
         if self.comm_stream is None or _needs_host_staging(self.send):
             self._ready = None  # synchronous path (gloo): everything happens in finish()

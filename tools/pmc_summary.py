@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc counter_collection CSVs (one directory per counter pass) into
-profiles/<tag>_pmc_summary.csv and profiles/traffic.json.
+profiles/<tag>_pmc_summary.csv and profiles/traffic.json (which records the hash of the kernel
+sources it was measured on: bench.py quotes it only while that hash matches the tree).
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and on gfx950
 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section;
@@ -65,8 +66,19 @@ def main():
     for kern in ("k_lsi", "k_pip"):
         if ("FETCH_SIZE", kern) in avg and ("WRITE_SIZE", kern) in avg:
             traffic[kern] = int((2 * avg[("FETCH_SIZE", kern)] + avg[("WRITE_SIZE", kern)]) * 1024)
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"))
-    print(out, traffic)
+    # instruction-issue evidence for the bench line's "limiter" (SQ passes, optional)
+    sq = {}
+    for d in sys.argv[4:]:
+        for counter, per_kernel in collect(d).items():
+            for kern in ("k_lsi", "k_pip"):
+                v = per_kernel.get(kern)
+                if v:
+                    sq.setdefault(kern, {})[counter] = sum(v) / len(v)
+    sys.path.insert(0, ROOT)
+    from rayjoin_amd._capi import kernel_source_hash
+    doc = {"tag": tag, "kernel_source_hash": kernel_source_hash(), "traffic": traffic, "sq": sq}
+    json.dump(doc, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    print(out, doc)
 
 
 if __name__ == "__main__":
