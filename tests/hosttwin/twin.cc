@@ -37,6 +37,15 @@ void twin_i128_to_double(int64_t hi, uint64_t lo, double* custom, double* compil
   *compiler = (double) v;
 }
 
+// rational<__int128>(num, den).simplify() (rational.h:87-90,198-203): out = {num hi, num lo, den hi, den lo}
+void twin_rat_make(int64_t nh, uint64_t nl, int64_t dh, uint64_t dl, uint64_t* out) {
+  const Rat r = rat_make((i128) (((u128) (uint64_t) nh << 64) | nl), (i128) (((u128) (uint64_t) dh << 64) | dl));
+  out[0] = (uint64_t) ((u128) r.num >> 64);
+  out[1] = (uint64_t) r.num;
+  out[2] = (uint64_t) ((u128) r.den >> 64);
+  out[3] = (uint64_t) r.den;
+}
+
 int twin_pip_better(double yy, double slope, uint32_t eid, double byy, double bslope, uint32_t beid, int q) {
   return pip_better(yy, slope, eid, byy, bslope, beid, q) ? 1 : 0;
 }

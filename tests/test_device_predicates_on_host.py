@@ -28,6 +28,7 @@ def twin():
     L.twin_lsi_stored.argtypes = [i64p, i64p, i64p]
     L.twin_pip_eval.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.twin_i128_to_double.argtypes = [C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.twin_rat_make.argtypes = [C.c_int64, C.c_uint64, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.twin_pip_better.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_uint32, C.c_int]
     return L
 
@@ -106,3 +107,43 @@ def test_custom_int128_to_double_is_the_compilers(twin):
             hi = (w >> 64) - (1 << 64) if (w >> 64) >= (1 << 63) else (w >> 64)
             twin.twin_i128_to_double(hi, w & ((1 << 64) - 1), C.byref(a), C.byref(b))
             assert a.value == b.value and np.signbit(a.value) == np.signbit(b.value), (sgn * v, a.value, b.value)
+
+
+def test_rational_simplify_is_exact(twin):
+    """rat_make (Euclid steps with a double-estimated quotient, 64-bit binary GCD, division by a
+    modular inverse) == the reference's rational(num, den).simplify() (rational.h:87-90,198-203:
+    Euclid gcd with '%', then num = sign(den) num / |g|, den = |den| / |g|) in exact integers:
+    map-like magnitudes (2^110 over 2^65), shared factors of every size, powers of two, extremes."""
+    import math
+    rng = np.random.default_rng(21)
+    out = (C.c_uint64 * 4)()
+    M = 1 << 128
+
+    def bits(n):
+        return int(rng.integers(0, 1 << 62)) | (int(rng.integers(0, 1 << 62)) << 62) | (int(rng.integers(0, 16)) << 124) if n > 62 \
+            else int(rng.integers(0, 1 << max(1, n)))
+
+    cases = []
+    for _ in range(3000):
+        nb, db, gb = int(rng.integers(1, 127)), int(rng.integers(1, 127)), int(rng.integers(0, 70))
+        g = (bits(gb) % (1 << gb) if gb else 1) or 1
+        n = (bits(nb) % (1 << nb)) // g * g
+        d = ((bits(db) % (1 << db)) // g * g) or g
+        if n >= 1 << 126 or d >= 1 << 126:
+            continue
+        cases.append((n * int(rng.choice([-1, 1])), d * int(rng.choice([-1, 1]))))
+    for k in range(1, 126):  # powers of two, near-powers, equal operands, zero numerators
+        cases += [(1 << k, 1 << (k // 2)), ((1 << k) - 1, (1 << k) - 1), (0, (1 << k) + 1), (-(1 << k), 3 << (k // 3)),
+                  ((1 << k) * 3, (1 << k) * 5), (3 ** 40 * (1 << (k % 60)), -(3 ** 25) * (1 << (k % 50)))]
+    cases += [((1 << 127) - 1, 1), (-(1 << 127) + 1, -1), (5, -(1 << 126)), (1 << 110, (1 << 65) + 1)]
+    for n, d in cases:
+        if abs(n) >= 1 << 127 or abs(d) >= 1 << 127 or d == 0:
+            continue
+        g = math.gcd(abs(n), abs(d))
+        wn, wd = (n if d > 0 else -n) // g, abs(d) // g
+        nn, dd = n % M, d % M
+        hi = lambda v: (v >> 64) - (1 << 64) if (v >> 64) >= (1 << 63) else (v >> 64)
+        twin.twin_rat_make(hi(nn), nn & ((1 << 64) - 1), hi(dd), dd & ((1 << 64) - 1), out)
+        gn, gd = (out[0] << 64) | out[1], (out[2] << 64) | out[3]
+        gn = gn - M if gn >= 1 << 127 else gn
+        assert (gn, gd) == (wn, wd), (n, d)
