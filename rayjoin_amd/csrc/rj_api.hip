@@ -36,7 +36,7 @@ struct BvhState {
   QBox* box0 = nullptr;
   int32_t* pmx1 = nullptr;
   uint32_t* occ = nullptr;
-  QBox* lvl[kMaxLevels] = {nullptr};
+  QBox* lvl[kMaxLevels] = {nullptr};  // boxes of level l, then one sibling-order word per node (rj_device.h)
   uint64_t nlvl[kMaxLevels] = {0};
   uint64_t alloc[kMaxLevels] = {0};
   int top = 0;
@@ -438,7 +438,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     if (!r) r = dev_alloc(h, &b.box0, b.n0p);
     if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
     if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
-    for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l]);
+    for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l] + b.alloc[l] / 2);  // 16 B box + 8 B order word per node
     if (r) { free_bvh(b); return r; }
   }
   // 1. Morton keys  2. radix sort (key, eid)  3. leaves + occupancy + level 1 in one pass  4. upper levels
@@ -463,6 +463,9 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       child = b.lvl[l];
       child_alloc = b.alloc[l];
     }
+    if (e != hipSuccess) break;
+    for (int l = 1; l <= top; l++)  // front-to-back sibling order of every level (k_pip)
+      if ((e = launch_sibling_order(h->stream, b.lvl[l], b.alloc[l], (uint64_t*) (b.lvl[l] + b.alloc[l]))) != hipSuccess) break;
     if (e != hipSuccess) break;
     toc(h, RJ_T_BUILD);
     e = hipStreamSynchronize(h->stream);

@@ -78,11 +78,17 @@ struct DeviceBvh {
   const int32_t* pmx1;    // [n0p] prefix max of box x1 inside each 64-block
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
+  // Behind the boxes of every level l (at lvl[l] + pad64(nlvl[l])) sits one 64-bit word per node:
+  // bit k set = sibling k (same 64-entry group) lies HIGHER (box centre, ties by index) -- the
+  // precomputed front-to-back order of an upward ray's traversal; see sibling_order().
   uint32_t nlvl[kMaxLevels];    // real node count per level
   int top;                // top level: nlvl[top] <= 64
   uint64_t n0;            // real segment count
 };
 
+__device__ __forceinline__ const uint64_t* sibling_order(const DeviceBvh& T, int l) {
+  return reinterpret_cast<const uint64_t*>(T.lvl[l] + (((uint64_t) T.nlvl[l] + 63) & ~(uint64_t) 63));
+}
 __device__ __forceinline__ int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
 }

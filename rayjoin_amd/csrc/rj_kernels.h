@@ -93,6 +93,7 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
                                int32_t* pmx1, QBox* lvl1, uint32_t* occ);
+hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks);
