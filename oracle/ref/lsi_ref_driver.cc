@@ -1,6 +1,7 @@
 // lsi_ref_driver.cc -- thin C entry points around the REFERENCE's own headers, compiled in
 // place from /root/reference/src (never copied): algo/lsi.h (intersect_test, both overloads),
-// util/rational.h (tcb::rational), grid/cell.h (calculate_cell), config.h.
+// util/rational.h (tcb::rational), grid/cell.h (calculate_cell), map/scaling.h +
+// map/bounding_box.h + util/type_traits.h (Scaling<double, int64_t, 17>), config.h.
 //
 // TEST INFRASTRUCTURE ONLY.  Built by oracle/Makefile target `ref` into oracle/_ref/ (git-ignored).
 // Used to (1) validate oracle/rj_oracle.c and (2) generate tests/golden/lsi_ref_vectors.json.
@@ -9,16 +10,26 @@
 // thrust CUDA backend, which this image lacks.  No stand-in header is written; instead its
 // include guard (RAYJOIN_UTIL_H) is pre-defined on the command line, and the seven macros its own
 // non-CUDA branch defines (DEV_HOST, DEV_HOST_INLINE, DEV_INLINE, MIN, MAX, MIN4, MAX4;
-// src/util/util.h:13-22) are given with -D.  Everything the predicate computes comes from the
-// reference sources.  The edge equation (map.h needs thrust) is formed here from
-// src/map/map.h:216-226's formula and the point type is ours (lsi.h is templated on POINT_T).
+// src/util/util.h:13-22) are given with -D.  util/type_traits.h includes <cuda_runtime.h> for the
+// vector types (long2, double2 ...): that header IS in this image -- NVIDIA's own, shipped inside
+// the triton package (oracle/Makefile finds it) -- so Scaling compiles against the real thing.
+// Everything the predicate and the scaling compute comes from the reference sources.  The edge
+// equation (map.h needs thrust) is formed here from src/map/map.h:216-226's formula and the point
+// type is ours (lsi.h is templated on POINT_T).  Compiled with -ffp-contract=off: Scaling is the
+// HOST build of the reference's class (separate multiply and add).
 #include <cstdint>
 #include <cstring>
+
+#include <cassert>
+#include <cstdio>
+#include <limits>
 
 #include "config.h"
 #include "util/rational.h"
 #include "algo/lsi.h"
 #include "grid/cell.h"
+#include "map/bounding_box.h"
+#include "map/scaling.h"
 
 namespace {
 struct Pt {
@@ -38,10 +49,12 @@ struct EdgeEq {
     }
   }
 };
-struct ScalingConsts {  // the two getters calculate_cell uses (src/map/scaling.h:108-122)
-  int64_t get_internal_range() const { return (INT64_MAX >> 17) - (INT64_MIN >> 17); }
-  int64_t get_internal_min() const { return INT64_MIN >> 17; }
-};
+using RefScaling = rayjoin::Scaling<double>;  // <double, int64_t, 17>; its getters feed calculate_cell
+RefScaling make_scaling(const double* bb) {
+  rayjoin::BoundingBox<double> b;
+  b.min_x = bb[0]; b.min_y = bb[1]; b.max_x = bb[2]; b.max_y = bb[3];
+  return RefScaling(b);
+}
 void put128(int64_t* out, __int128 v) {
   out[0] = (int64_t) (unsigned __int128) v;
   out[1] = (int64_t) ((unsigned __int128) v >> 64);
@@ -71,7 +84,7 @@ int ref_intersect_point_segs(const int64_t* s1, const int64_t* s2, int gsize, in
   xs.y = y;
   out[8] = xs.x.num();
   out[9] = xs.y.num();
-  ScalingConsts sc;
+  const RefScaling sc;  // default constructor: the internal range only (scaling.h:43-54)
   out[10] = rayjoin::dev::calculate_cell(gsize, sc, x);
   out[11] = rayjoin::dev::calculate_cell(gsize, sc, y);
   out[12] = xs.x.denom();
@@ -81,11 +94,36 @@ int ref_intersect_point_segs(const int64_t* s1, const int64_t* s2, int gsize, in
 }
 
 int ref_cell_of_int(int gsize, int64_t v) {
-  ScalingConsts sc;
+  const RefScaling sc;  // default constructor: the internal range only (scaling.h:43-54)
   return rayjoin::dev::calculate_cell(gsize, sc, v);
 }
 int ref_cell_of_double(int gsize, double v) {
-  ScalingConsts sc;
+  const RefScaling sc;  // default constructor: the internal range only (scaling.h:43-54)
   return rayjoin::dev::calculate_cell(gsize, sc, v);
+}
+
+// Scaling(bb).ScaleX/ScaleY over n points (src/map/scaling.h:56-93)
+void ref_scale_points(const double* bb, const double* xy, uint64_t n, int64_t* out) {
+  const RefScaling s = make_scaling(bb);
+  for (uint64_t i = 0; i < n; i++) {
+    out[2 * i] = s.ScaleX(xy[2 * i]);
+    out[2 * i + 1] = s.ScaleY(xy[2 * i + 1]);
+  }
+}
+// Scaling(bb).UnscaleX/UnscaleY (src/map/scaling.h:95-106)
+void ref_unscale_points(const double* bb, const int64_t* xy, uint64_t n, double* out) {
+  const RefScaling s = make_scaling(bb);
+  for (uint64_t i = 0; i < n; i++) {
+    out[2 * i] = s.UnscaleX(xy[2 * i]);
+    out[2 * i + 1] = s.UnscaleY(xy[2 * i + 1]);
+  }
+}
+// {internal_min, internal_max, internal_range, sizeof(Scaling)}
+void ref_scaling_consts(int64_t* out) {
+  const RefScaling s;
+  out[0] = s.get_internal_min();
+  out[1] = s.get_internal_max();
+  out[2] = s.get_internal_range();
+  out[3] = (int64_t) sizeof(RefScaling);
 }
 }

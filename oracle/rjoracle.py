@@ -104,6 +104,9 @@ def ref_lib():
     R.ref_intersect_point_segs.argtypes = [_i64p, _i64p, C.c_int, _i64p]
     R.ref_cell_of_int.argtypes = [C.c_int, C.c_int64]
     R.ref_cell_of_double.argtypes = [C.c_int, C.c_double]
+    R.ref_scale_points.argtypes = [_f64p, _f64p, C.c_uint64, _i64p]
+    R.ref_unscale_points.argtypes = [_f64p, _i64p, C.c_uint64, _f64p]
+    R.ref_scaling_consts.argtypes = [_i64p]
     _ref = R
     return R
 
