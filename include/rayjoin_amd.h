@@ -195,7 +195,13 @@ typedef enum {
   RJ_T_PIP_KERNEL = 2,/* the PIP kernel of the last rj_pip_query* */
   RJ_T_LSI_POINTS = 3,
   RJ_T_SORT = 4,
-  RJ_T_ORDER = 5      /* Morton re-ordering of an incoherent query set inside the last query, if any */
+  RJ_T_ORDER = 5,     /* Morton re-ordering of an incoherent query set inside the last query, if any */
+  /* stages of the last rj_build_lbvh (the reference prints its own under -profile,
+   * deps/lbvh/lbvh/bvh.cuh:464-474): sort keys, radix sort, leaf pass, upper levels + sibling order */
+  RJ_T_BUILD_KEYS = 6,
+  RJ_T_BUILD_SORT = 7,
+  RJ_T_BUILD_LEAVES = 8,
+  RJ_T_BUILD_LEVELS = 9
 } rj_timer;
 /* HIP-event time (ms) of the last launch of that stage on the handle's stream; syncs. */
 int rj_last_ms(rj_handle h, int which, float* ms);

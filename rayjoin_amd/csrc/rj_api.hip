@@ -51,7 +51,7 @@ struct GridState {  // -mode=grid: one CSR per map (rj_grid.hip)
   uint64_t total = 0;
 };
 
-constexpr int kNumTimers = 6;
+constexpr int kNumTimers = 10;
 // average (w + h) of a 64-query group's quantised box above which the query set is re-ordered
 // along the Morton curve before the kernels run (the domain is 2^31 wide per axis)
 constexpr unsigned long long kIncoherentExtent = 1ull << 28;
@@ -448,14 +448,21 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   uint32_t *v_in = h->ord_vin, *v_out = h->ord_vout;
   hipError_t e = hipSuccess;
   do {
+    tic(h, RJ_T_BUILD_KEYS);
     if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
+    toc(h, RJ_T_BUILD_KEYS);
+    tic(h, RJ_T_BUILD_SORT);
     if (m.ne) {
       size_t tb = h->ord_temp_bytes;
       if ((e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
     }
+    toc(h, RJ_T_BUILD_SORT);
+    tic(h, RJ_T_BUILD_LEAVES);
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p / 64, b.alloc[1],
                                  b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.lvl[1], b.occ)) != hipSuccess) break;
+    toc(h, RJ_T_BUILD_LEAVES);
+    tic(h, RJ_T_BUILD_LEVELS);
     const QBox* child = b.lvl[1];
     uint64_t child_alloc = b.alloc[1];
     for (int l = 2; l <= top; l++) {
@@ -467,6 +474,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     for (int l = 1; l <= top; l++)  // front-to-back sibling order of every level (k_pip)
       if ((e = launch_sibling_order(h->stream, b.lvl[l], b.alloc[l], (uint64_t*) (b.lvl[l] + b.alloc[l]))) != hipSuccess) break;
     if (e != hipSuccess) break;
+    toc(h, RJ_T_BUILD_LEVELS);
     toc(h, RJ_T_BUILD);
     e = hipStreamSynchronize(h->stream);
   } while (0);

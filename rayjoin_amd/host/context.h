@@ -83,6 +83,27 @@ struct HostMap {
   }
 };
 
+// Stream (src/util/stream.h:13-27): the stream a Query is enqueued on.  The reference's owns a
+// non-blocking cudaStream_t; here it names either the handle's own non-blocking stream (what
+// Context::get_stream() returns) or a caller-owned hipStream_t, and Query(stream, ...) points the
+// handle at it through rj_set_stream.
+class Stream {
+ public:
+  explicit Stream(rj_handle h) : h_(h), own_(true) {}
+  Stream(rj_handle h, void* hip_stream) : h_(h), native_(hip_stream), own_(false) {}
+  void Sync() const { rj_check(h_, rj_sync(h_), "rj_sync"); }
+  // make the handle work on this stream
+  void Bind() const {
+    rj_check(h_, own_ ? rj_set_option(h_, "own_stream", 1) : rj_set_stream(h_, native_), "rj_set_stream");
+  }
+  void* native() const { return native_; }
+
+ private:
+  rj_handle h_;
+  void* native_ = nullptr;
+  bool own_;
+};
+
 class Context {
  public:
   explicit Context(const std::array<std::shared_ptr<PlanarGraph>, 2>& pgs, int device = 0) : pgraphs_(pgs) {
@@ -96,6 +117,7 @@ class Context {
               << ", " << bb_.max_y << ")" << std::endl;
     int rc = rj_create(device, &h_);
     if (rc != RJ_OK) throw RjError(rc, "rj_create failed: no usable HIP device (the HIP path is the only compute path)");
+    stream_.reset(new Stream(h_));
   }
   ~Context() { if (h_) rj_destroy(h_); }
   Context(const Context&) = delete;
@@ -126,8 +148,10 @@ class Context {
   const Scaling& get_scaling() const { return scaling_; }
   const BoundingBox& get_bounding_box() const { return bb_; }
   rj_handle handle() { return h_; }
+  Stream& get_stream() { return *stream_; }  // context.h:119
 
  private:
+  std::unique_ptr<Stream> stream_;
   std::array<std::shared_ptr<PlanarGraph>, 2> pgraphs_;
   std::array<std::shared_ptr<HostMap>, 2> maps_;
   BoundingBox bb_;

@@ -2,9 +2,10 @@
 //   LSI  {Init, Query, get_xsects, CopyTo}     src/app/lsi.h:8-43, src/app/lsi_lbvh.h:17-98
 //   PIP  {Init, Query, get_closest_eids}       src/app/pip.h:9-38, src/app/pip_lbvh.h:14-142
 //   LSIGrid / PIPGrid                          src/app/lsi_grid.h:80-131, src/app/pip_grid.h:14-70
-// Same method names, argument meaning and lifetime rules (results stay valid until the next
-// Query or destruction); errors are exceptions carrying the C-ABI status (the reference throws
-// from CUDA_CHECK, src/util/exception.h:150-158); a full queue throws instead of being UB.
+// Same method names, signatures (Query(Stream&, int query_map_id[, points]), src/app/lsi.h:27,
+// src/app/pip.h:24), argument meaning and lifetime rules (results stay valid until the next Query or
+// destruction); errors are exceptions carrying the C-ABI status (the reference throws from
+// CUDA_CHECK, src/util/exception.h:150-158); a full queue throws instead of being UB.
 #pragma once
 #include <vector>
 
@@ -22,7 +23,7 @@ class LSI {
     cap_ = max_n_xsects;
     rj_check(ctx_.handle(), rj_dev_alloc(ctx_.handle(), 8 * (cap_ ? cap_ : 1), (void**) &queue_), "rj_dev_alloc");
   }
-  virtual void Query(int query_map_id) = 0;
+  virtual void Query(Stream& stream, int query_map_id) = 0;
   size_t size() const { return n_; }
   size_t local_size() const { return n_local_; }
   // restrict Query to the eid range of this rank's shard of the query map (default: every edge)
@@ -67,7 +68,8 @@ class LSI {
 class LSILBVH : public LSI {
  public:
   explicit LSILBVH(Context& ctx) : LSI(ctx) {}
-  void Query(int query_map_id) override {
+  void Query(Stream& stream, int query_map_id) override {
+    stream.Bind();
     uint64_t n = 0;
     const size_t qb = ranged_ ? e0_ : 0, qe = ranged_ ? e1_ : ctx_.get_map(query_map_id)->n_edges();
     int rc = rj_lsi_query(ctx_.handle(), 1 - query_map_id, query_map_id, qb, qe, cap_, queue_, &n);
@@ -81,7 +83,8 @@ class LSILBVH : public LSI {
 class LSIGrid : public LSI {
  public:
   explicit LSIGrid(Context& ctx) : LSI(ctx) {}
-  void Query(int /*query_map_id*/) override {
+  void Query(Stream& stream, int /*query_map_id*/) override {
+    stream.Bind();
     if (ranged_ && !(e0_ == 0 && e1_ == ctx_.get_map(1)->n_edges()))
       throw RjError(RJ_E_INVALID, "LSIGrid: -mode=grid joins the two whole maps (no shards)");
     uint64_t n = 0;
@@ -101,7 +104,7 @@ class PIP {
     rj_check(ctx_.handle(), rj_dev_alloc(ctx_.handle(), 4 * (cap_ ? cap_ : 1), (void**) &faces_), "rj_dev_alloc");
   }
   // query_points_dev == nullptr: every vertex of the query map (RunPIPQuery, run_query.cu:346)
-  virtual void Query(int query_map_id, const int64_t* query_points_dev, size_t n) = 0;
+  virtual void Query(Stream& stream, int query_map_id, const int64_t* query_points_dev, size_t n) = 0;
   void get_closest_eids(std::vector<uint32_t>& out) {
     out.resize(n_);
     rj_check(ctx_.handle(), rj_memcpy_d2h(ctx_.handle(), out.data(), closest_, 4 * n_), "rj_memcpy_d2h");
@@ -121,7 +124,8 @@ class PIP {
 class PIPLBVH : public PIP {
  public:
   explicit PIPLBVH(Context& ctx) : PIP(ctx) {}
-  void Query(int query_map_id, const int64_t* query_points_dev, size_t n) override {
+  void Query(Stream& stream, int query_map_id, const int64_t* query_points_dev, size_t n) override {
+    stream.Bind();
     if (n > cap_) throw RjError(RJ_E_INVALID, "PIP::Query: more points than Init() reserved");
     rj_check(ctx_.handle(), rj_pip_query(ctx_.handle(), 1 - query_map_id, query_map_id, query_points_dev, 0, n,
                                          closest_, faces_), "rj_pip_query");
@@ -132,7 +136,8 @@ class PIPLBVH : public PIP {
 class PIPGrid : public PIP {
  public:
   explicit PIPGrid(Context& ctx) : PIP(ctx) {}
-  void Query(int query_map_id, const int64_t* query_points_dev, size_t n) override {
+  void Query(Stream& stream, int query_map_id, const int64_t* query_points_dev, size_t n) override {
+    stream.Bind();
     if (n > cap_) throw RjError(RJ_E_INVALID, "PIP::Query: more points than Init() reserved");
     rj_check(ctx_.handle(), rj_pip_query_grid(ctx_.handle(), 1 - query_map_id, query_map_id, query_points_dev, 0, n,
                                               closest_, faces_), "rj_pip_query_grid");

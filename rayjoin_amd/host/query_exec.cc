@@ -101,6 +101,69 @@ void ApplySampling(const Flags& f, std::shared_ptr<PlanarGraph>& base, std::shar
   if (!f.sample_output.empty()) serialize_pgraph(**target, f.sample_output.c_str());
 }
 
+// -profile: per-stage index build times, the analogue of the reference's "LBVH Profiling result"
+// (deps/lbvh/lbvh/bvh.cuh:464-474) / grid profile (src/grid/uniform_grid.h:238-244), from HIP events
+void PrintBuildProfile(Context& ctx, bool grid) {
+  rj_handle h = ctx.handle();
+  float total = 0;
+  rj_last_ms(h, RJ_T_BUILD, &total);
+  if (grid) {
+    printf("Grid Profiling result:\nTotal: %.3lf\n", (double) total);
+    return;
+  }
+  float keys = 0, sort = 0, leaves = 0, levels = 0;
+  rj_last_ms(h, RJ_T_BUILD_KEYS, &keys);
+  rj_last_ms(h, RJ_T_BUILD_SORT, &sort);
+  rj_last_ms(h, RJ_T_BUILD_LEAVES, &leaves);
+  rj_last_ms(h, RJ_T_BUILD_LEVELS, &levels);
+  printf("LBVH Profiling result:\nSort keys (Hilbert): %.3lf\nRadix sort: %.3lf\nLeaf blocks (gather, boxes, "
+         "occupancy bitmap): %.3lf\nUpper levels + sibling order: %.3lf\nTotal: %.3lf\n",
+         (double) keys, (double) sort, (double) leaves, (double) levels, (double) total);
+}
+
+// CheckPIPResult (run_query.cu:22-99): run the grid PIP on the same points and compare.  A different
+// eid is not yet a wrong answer -- two edges may have the same coordinates -- so differing eids are
+// compared by the scaled endpoints of their edges, as the reference does.
+bool CheckPIPResult(Context& ctx, const Flags& f, const int64_t* d_pts, size_t n_points, const std::vector<uint32_t>& res) {
+  rj_handle h = ctx.handle();
+  std::cerr << "Checking point in polygon" << std::endl;
+  rj_check(h, rj_build_grid(h, 0, f.grid_size), "rj_build_grid");
+  PIPGrid pip_grid(ctx);
+  pip_grid.Init(n_points);
+  pip_grid.Query(ctx.get_stream(), 1, d_pts, n_points);
+  std::vector<uint32_t> ans;
+  pip_grid.get_closest_eids(ans);
+  auto base = ctx.get_map(0);
+  auto endpoints = [&](uint32_t eid, int64_t out[4]) {  // eid = p_idx - ichain (map.h:198-207)
+    size_t lo = 0, hi = base->n_chains();          // largest chain c with row_index[c] - c <= eid
+    while (hi - lo > 1) {
+      size_t mid = (lo + hi) / 2;
+      if ((size_t) base->row_index[mid] - mid <= eid) lo = mid; else hi = mid;
+    }
+    const size_t p = (size_t) eid + lo;
+    out[0] = base->xy[2 * p]; out[1] = base->xy[2 * p + 1]; out[2] = base->xy[2 * p + 2]; out[3] = base->xy[2 * p + 3];
+  };
+  size_t n_diff = 0;
+  for (size_t i = 0; i < n_points; i++) {
+    if (ans[i] == res[i]) continue;
+    bool diff = (ans[i] == RJ_MISS_EID) != (res[i] == RJ_MISS_EID);
+    if (!diff) {
+      int64_t a[4], b[4];
+      endpoints(ans[i], a);
+      endpoints(res[i], b);
+      diff = a[0] != b[0] || a[1] != b[1] || a[2] != b[2] || a[3] != b[3];
+    }
+    if (diff && n_diff < 10) printf("point %zu ans %u, res %u\n", i, ans[i], res[i]);
+    n_diff += diff;
+  }
+  if (n_diff)
+    std::cerr << "Map: 0 Total points: " << n_points << " n diff: " << n_diff << " Error rate: "
+              << (double) n_diff / n_points * 100 << " %" << std::endl;
+  else
+    std::cerr << "Map: 0 passed check" << std::endl;
+  return n_diff == 0;
+}
+
 void CheckMode(const Flags& f) {
   if (f.mode == "lbvh" || f.mode == "grid") return;
   if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
@@ -151,13 +214,15 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
   } else {
     rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
   }
+  if (f.profile) PrintBuildProfile(*ctx, grid);
   tm.next("Warmup");
-  for (int i = 0; i < f.warmup; i++) lsi.Query(1);
+  Stream& stream = ctx->get_stream();
+  for (int i = 0; i < f.warmup; i++) lsi.Query(stream, 1);
   tm.next("Query", f.repeat);
   float kernel_ms = 0;
   for (int i = 0; i < f.repeat; i++) {
     if (f.v) std::cerr << "Iter: " << i << std::endl;
-    lsi.Query(1);
+    lsi.Query(stream, 1);
     float ms = 0;
     rj_last_ms(ctx->handle(), RJ_T_LSI_KERNEL, &ms);
     kernel_ms += ms;
@@ -220,19 +285,26 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
     rj_check(ctx->handle(), rj_build_grid(ctx->handle(), 0, f.grid_size), "rj_build_grid");
   else
     rj_check(ctx->handle(), rj_build_lbvh(ctx->handle(), 0), "rj_build_lbvh");
+  if (f.profile) PrintBuildProfile(*ctx, grid);
   tm.next("Warmup");
-  for (int i = 0; i < f.warmup; i++) pip.Query(1, d_pts, n_points);
+  Stream& stream = ctx->get_stream();
+  for (int i = 0; i < f.warmup; i++) pip.Query(stream, 1, d_pts, n_points);
   tm.next("Query", f.repeat);
   float kernel_ms = 0;
   for (int i = 0; i < f.repeat; i++) {
-    pip.Query(1, d_pts, n_points);
+    pip.Query(stream, 1, d_pts, n_points);
     float ms = 0;
     rj_last_ms(ctx->handle(), RJ_T_PIP_KERNEL, &ms);
     kernel_ms += ms;
   }
-  tm.next("Cleanup");
   std::vector<uint32_t> eids;
   pip.get_closest_eids(eids);
+  bool check_ok = true;
+  if (f.check && !grid) {  // run_query.cu:449-455
+    tm.next("Check");
+    check_ok = CheckPIPResult(*ctx, f, d_pts, n_points, eids);
+  }
+  tm.next("Cleanup");
   size_t hits = 0;
   for (auto e : eids) hits += e != RJ_MISS_EID;
   std::cerr << "Points: " << n_points << " Hits: " << hits << std::endl;
@@ -247,6 +319,7 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   }
   if (d_pts) rj_dev_free(ctx->handle(), d_pts);
   tm.end();
+  if (!check_ok) throw std::runtime_error("-check: the LBVH result differs from -mode=grid");
 }
 
 }  // namespace

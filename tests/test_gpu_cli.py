@@ -94,3 +94,35 @@ def test_native_rccl_allgatherv_single_rank(oracle, tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert re.search(r"all ranks (\d+)", r.stderr)
+
+
+def test_query_exec_pip_check_and_profile(tmp_path):
+    """-check (default on, like src/flags.cc:9): RunPIPQuery re-runs the points through the device grid
+    and compares by edge ENDPOINTS where eids differ (run_query.cu:22-99) -- a map with every chain
+    stored twice has equal-geometry edges with different eids, which must still pass.  -profile prints
+    the index build stages (deps/lbvh/lbvh/bvh.cuh:464-474)."""
+    g0, g1 = synth.lattice_map(7, 60, 61), synth.lattice_map(15, 30, 62)
+    # duplicate every chain of the base map: same coordinates, different eids
+    dup = maps.PlanarGraph(np.concatenate([g0.chains, g0.chains]),
+                           np.concatenate([g0.row_index[:-1], g0.row_index + g0.n_points]).astype(np.uint32),
+                           np.concatenate([g0.points, g0.points]))
+    p0, p1 = str(tmp_path / "a.cdb"), str(tmp_path / "b.cdb")
+    maps.write_cdb(p0, dup, "%.9f")
+    maps.write_cdb(p1, g1, "%.9f")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "pip", "-mode", "lbvh", "-warmup", "0", "-repeat", "1",
+                        "-grid_size", "256", "-profile"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Checking point in polygon" in r.stderr and "Map: 0 passed check" in r.stderr
+    assert re.search(r" - Check: [0-9.e+-]+ ms", r.stderr)
+    assert "LBVH Profiling result:" in r.stdout and re.search(r"Radix sort: [0-9.]+", r.stdout) and re.search(r"Total: [0-9.]+", r.stdout)
+    # -nocheck skips the phase; -mode=grid never checks itself (run_query.cu:452)
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "pip", "-mode", "lbvh", "-warmup", "0", "-repeat", "1",
+                        "-nocheck"], capture_output=True, text=True)
+    assert r.returncode == 0 and "passed check" not in r.stderr and " - Check:" not in r.stderr
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "pip", "-mode", "grid", "-grid_size", "256", "-warmup", "0",
+                        "-repeat", "1"], capture_output=True, text=True)
+    assert r.returncode == 0 and "passed check" not in r.stderr
+    # generated points (no -poly2) are checked too
+    r = subprocess.run([EXE, "-poly1", p0, "-query", "pip", "-mode", "lbvh", "-gen_n", "5000", "-seed", "4", "-warmup", "0",
+                        "-repeat", "1", "-grid_size", "256"], capture_output=True, text=True)
+    assert r.returncode == 0 and "Map: 0 passed check" in r.stderr
