@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
             // A certain hit that ends below the start of the one certain hit held so far replaces it
             // (that one is certainly higher): the lane keeps ONE candidate and skips the arithmetic
             // at the end, whatever order the blocks were visited in.
-            const bool replace = certain && sure1 && sy1 < sure_y0;
+            const bool replace = certain && sure1 && cnt == 1 && sy1 < sure_y0;  // (sure1 may be stale once an evaluation has emptied the list)
             L.cand[replace ? 0 : cnt][lane] = slot0 + (uint32_t) jj;
             sure1 = replace || (cnt == 0 && certain);
             sure_y0 = sure1 ? sy0 : sure_y0;
