@@ -64,7 +64,7 @@ def read_cdb(path):
     chains, row_index, pts = [], [], []
     np_left = 0
     last = None
-    with open(path, "r") as f:
+    with open(path, "r", newline="\n") as f:  # (std::getline splits at '\n' only: a '\r' stays in the line)
         for lno, line in enumerate(f, 1):
             line = line.rstrip("\n")
             if not line or line[0] in "#%":
@@ -75,8 +75,8 @@ def read_cdb(path):
                     if len(tok) < 6:
                         raise ValueError
                     cid, n, first, lastp, left, right = (int(t) for t in tok[:6])
-                    if n < 2:
-                        raise ValueError
+                    if n < 2 or any(not -(1 << 63) <= v < (1 << 63) for v in (cid, n, first, lastp, left, right)):
+                        raise ValueError  # (an istream fails on an integer that does not fit int64_t)
                     chains.append((cid, first, lastp, left, right))
                     row_index.append(len(pts))
                     np_left = n
@@ -85,6 +85,8 @@ def read_cdb(path):
                     if len(tok) < 2:
                         raise ValueError
                     p = (float(tok[0]), float(tok[1]))
+                    if not (np.isfinite(p[0]) and np.isfinite(p[1])):
+                        raise ValueError  # (an istream reads neither "inf"/"nan" nor an out-of-range number)
                     if last is not None and p == last:
                         raise ValueError
                     pts.append(p)
