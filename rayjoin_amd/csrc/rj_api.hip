@@ -23,6 +23,7 @@ struct MapState {
   int64_t* pts = nullptr;
   Seg* seg = nullptr;
   uint32_t* edge_chain = nullptr;
+  uint32_t* ccode = nullptr;  // 4-byte cell code per edge (k_lsi's pre-filter stream)
   uint32_t* left = nullptr;
   uint32_t* right = nullptr;
 };
@@ -135,7 +136,7 @@ int dev_alloc(rj_handle h, T** p, uint64_t count) {
 }
 
 void free_map(MapState& m) {
-  (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.left); (void) hipFree(m.right);
+  (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.ccode); (void) hipFree(m.left); (void) hipFree(m.right);
   m = MapState();
 }
 
@@ -335,6 +336,7 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (!rc) rc = dev_alloc(h, &m.pts, 2 * np + 2);
   if (!rc) rc = dev_alloc(h, &m.seg, m.ne);
   if (!rc) rc = dev_alloc(h, &m.edge_chain, m.ne);
+  if (!rc) rc = dev_alloc(h, &m.ccode, m.ne);
   if (!rc) rc = dev_alloc(h, &m.left, nc);
   if (!rc) rc = dev_alloc(h, &m.right, nc);
   if (!rc) rc = dev_alloc(h, &d_eb, nc + 1);
@@ -344,7 +346,7 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
     if (e == hipSuccess && nc) e = hipMemcpyAsync(d_eb, eb.data(), 4 * (nc + 1), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && nc) e = hipMemcpyAsync(m.left, l32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && nc) e = hipMemcpyAsync(m.right, r32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, d_eb, (uint32_t) nc, m.ne, m.seg, m.edge_chain);
+    if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, d_eb, (uint32_t) nc, m.ne, m.seg, m.edge_chain, m.ccode);
     // whatever was enqueued reads the host vectors and d_eb: drain the stream before they go away
     const hipError_t es = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = es;
@@ -535,6 +537,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   LsiArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.qseg = h->map[query_map_id].seg;
+  a.qcode = h->map[query_map_id].ccode;
   a.order = order;
   a.qbeg = qb; a.qend = qe;
   a.base_is_map0 = base_map_id == 0;

@@ -15,6 +15,7 @@ static_assert(sizeof(Seg) == 32 && sizeof(QBox) == 16, "layout");
 struct LsiArgs {
   DeviceBvh bvh;
   const Seg* qseg;     // query map segments in eid order
+  const uint32_t* qcode; // their 4-byte cell codes (the pre-filter's stream)
   const uint32_t* order; // nullable: Morton-sorted positions (relative to qbeg) for incoherent query sets
   uint64_t qbeg, qend; // query eid range
   int base_is_map0;
@@ -75,7 +76,7 @@ hipError_t launch_lsi_grid(hipStream_t st, const GridLsiArgs& a);
 hipError_t launch_pip_grid(hipStream_t st, const GridPipArgs& a);
 
 hipError_t launch_build_segs(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin,
-                             uint32_t nc, uint64_t ne, Seg* seg, uint32_t* edge_chain);
+                             uint32_t nc, uint64_t ne, Seg* seg, uint32_t* edge_chain, uint32_t* ccode);
 hipError_t launch_morton(hipStream_t st, const Seg* seg, uint64_t ne, MortonKey* keys, uint32_t* vals);
 hipError_t sort_morton_pairs(hipStream_t st, void* temp, size_t& temp_bytes, const MortonKey* kin, MortonKey* kout,
                              const uint32_t* vin, uint32_t* vout, uint64_t n);
