@@ -791,13 +791,14 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
     const uint64_t ipos = g * GL + lane;  // position in the (possibly Morton-sorted) query order
     const bool valid = (uint32_t) lane < GL && ipos < A.n;
     const uint64_t ip = A.order ? (valid ? A.order[ipos] : 0) : ipos;
-    int64_t px = 0, py = 0;
+    // The traversal works on the quantised point; the exact coordinates are read again (an L2 hit)
+    // by the few lanes whose candidates need the exact arithmetic -- 0.2 per group on the headline
+    // workload -- instead of occupying four of the kernel's 80 registers throughout.
+    int32_t qx = 0, qy = 0;
     if (valid) {
-      // streamed once: keep it out of the way of the tree levels that live in L2
-      px = __builtin_nontemporal_load(A.pts + 2 * ip);
-      py = __builtin_nontemporal_load(A.pts + 2 * ip + 1);
+      qx = quant(A.pts[2 * ip]);
+      qy = quant(A.pts[2 * ip + 1]);
     }
-    const int32_t qx = quant(px), qy = quant(py);
     const int32_t qym1 = qy > 0 ? qy - 1 : 0;
     const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
     const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
@@ -821,6 +822,11 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
         cnt = 0;
       }
       const int maxc = wave_max(cnt);
+      int64_t px = 0, py = 0;
+      if (cnt > 0) {
+        px = A.pts[2 * ip];
+        py = A.pts[2 * ip + 1];
+      }
       for (int r = 0; r < maxc; r++) {
         if (r < cnt) {
           const uint32_t slot = L.cand[r][lane];
