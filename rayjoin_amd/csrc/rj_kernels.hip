@@ -847,6 +847,10 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
       }
       if (STATS) st_tests += (unsigned long long) __popcll(__ballot(cnt > 0));
       cnt = 0;
+      if (final_round) {  // nothing left to prune
+        if (STATS) tk_drain += clock64() - tk0;
+        return;
+      }
       if (best_slot != 0xFFFFFFFFu && best_yy < __builtin_inf()) {
         // exact best known: tighten the integer bound (conservative: +1 quantum)
         double t = (best_yy + (double) kCoordOffset) * (1.0 / 65536.0);
@@ -926,6 +930,7 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
         const int32_t pm = T.pmx1[(uint64_t) slot0 + lane];
         if (STATS) st_leaf++;
         // (lanes whose ray cannot use this block any more, or never could, sit the visit out: `want`)
+        const int32_t qbest_before = qbest;
         const int ub = wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
         int j = want ? ub - 1 : -1;
         const int cnt_before = cnt;
@@ -956,7 +961,7 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
         }
         if (STATS && !__ballot(cnt != cnt_before)) st_leaf_nocand++;
         const int32_t gbest_before = gbest;
-        gbest = wave_max(qbest);
+        if (__ballot(qbest != qbest_before)) gbest = wave_max(qbest);  // (a visit without a certain hit changes no bound)
         if (gbest < gbest_before && sp > 1) {
           // The bound of the whole group dropped: sweep the stack once, 64 entries per pass, and
           // drop every entry that starts above it (order preserved).  One pass replaces a dozen
