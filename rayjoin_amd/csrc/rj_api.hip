@@ -660,11 +660,12 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // "pip_concurrent": the kernel goes to the handle's second stream and overlaps whatever runs on
   // the main one (the LSI kernel of the same step: both only read the maps and the tree).  Not
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
-  // Measured (USCounty x BlockGroup shards, bench.py --emulate-shard): two full-size persistent
-  // kernels only get in each other's way (1.85 vs 1.65 ms per step), a 1/8 shard gains 7 % because
-  // each kernel alone leaves the chip half idle in its ramp and tail; "auto" draws the line at
-  // ~16 groups per resident wave.
-  const bool small = n < (uint64_t) 6000000;
+  // Measured (USCounty x BlockGroup shards, tools/overlap_probe.py, whole step): beside the LSI kernel
+  // a 1/8 shard's step takes 0.34 instead of 0.44 ms, a 1/4 shard's 0.56 instead of 0.62, a 1/2
+  // shard's 0.94 instead of 0.96 -- each kernel alone leaves the chip partly idle in its ramp and
+  // tail -- while two full-size persistent kernels only get in each other's way (1.64 vs 1.58 ms);
+  // "auto" draws the line at 16 M points.
+  const bool small = n < (uint64_t) 16000000;
   const bool aux = (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && small)) && !order && !h->stats_on;
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be

@@ -1129,6 +1129,14 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
   uint64_t ngroups = (a.qend - a.qbeg + a.group_lanes - 1) / a.group_lanes;
   uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
+  // A small query set (a shard of an 8-GPU run) is faster on FEWER resident waves: with under ~20
+  // groups per wave the kernel is all ramp -- every wave's first groups miss the caches together --
+  // and two thirds of the groups are dismissed by the pre-filter anyway.  Measured (1/16, 1/8, 1/4
+  // of the headline query map): 768-1024 blocks beat the full grid by 22 / 18 / 7 %; from 1/2 up the
+  // full grid wins.  (k_pip is fastest on the full grid at every size.)
+  const uint64_t by_work = ngroups / (4 * 20);
+  const int floor_blocks = 512 < grid ? 512 : grid;
+  if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
   if (stats)
     hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a);
   else
