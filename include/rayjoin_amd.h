@@ -213,7 +213,7 @@ int rj_last_ms(rj_handle h, int which, float* ms);
  * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
 int rj_last_stats(rj_handle h, uint64_t stats[16]);
 /* options: "stats" 0/1 (instrumented kernels); "chunk_groups" n (consecutive groups handed to a
- * wave at a time, default 4); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
+ * wave at a time; 0 = automatic, the default: 8 for LSI, 4 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
  * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
  * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
  * consecutive queries are spatially scattered, e.g. the generated workloads of

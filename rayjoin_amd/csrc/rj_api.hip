@@ -93,7 +93,7 @@ struct rj_handle_s {
   void* ord_temp = nullptr;
   size_t ord_temp_bytes = 0;
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
-  int chunk_groups = 4;      // consecutive groups handed to a wave at a time
+  int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 4: measured optima)
   int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
   uint64_t last_stats[16] = {0};
   // grow-only arena for the overlay pass (carved per call, no per-call hipMalloc/hipFree)
@@ -289,7 +289,7 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     return RJ_OK;
   }
   if (!strcmp(name, "chunk_groups")) {
-    if (value < 1 || value > 4096) return fail(h, RJ_E_INVALID, "chunk_groups out of range");
+    if (value < 0 || value > 4096) return fail(h, RJ_E_INVALID, "chunk_groups out of range (0 = automatic)");
     h->chunk_groups = (int) value;
     return RJ_OK;
   }
@@ -544,7 +544,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.out = pairs_dev; a.cap = capacity;
   a.counter = h->d_counter;
   a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi);
-  a.chunk_groups = (uint32_t) h->chunk_groups;
+  a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 8);
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
@@ -680,7 +680,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.query_map_id = query_map_id;
   a.closest = closest_eid_dev; a.face = face_id_dev;
   a.work_counter = (unsigned int*) sched;
-  a.chunk_groups = (uint32_t) h->chunk_groups;
+  a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 4);
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
