@@ -269,8 +269,8 @@ def main():
                 # already the algorithmic minimum
                 avail = c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
                 roof[name]["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] / avail, 3)
-                if c.get("SQ_ACTIVE_INST_SCA"):
-                    roof[name]["salu_busy_frac"] = round(c["SQ_ACTIVE_INST_SCA"] / (c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 256.0), 3)
+                if c.get("SQ_ACTIVE_INST_SCA"):  # (same normalisation: scalar-issue quad-cycles per SIMD's waves)
+                    roof[name]["salu_busy_frac"] = round(c["SQ_ACTIVE_INST_SCA"] / avail, 3)
                 if roof[name]["valu_busy_frac"] > 0.6:
                     roof[name]["limiter"] = "valu-issue"
         dom = "lsi" if lsi_k >= pip_k else "pip"

@@ -32,5 +32,12 @@ def test_committed_bench_line_has_the_contract_fields():
 
 
 def test_traffic_file_matches_the_kernels_bench_reports():
+    """profiles/traffic.json carries the PMC evidence bench.py quotes AND the hash of the kernel
+    sources it was measured on; bench.py ignores it when that hash is not the tree's."""
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert set(t) == {"k_lsi", "k_pip"} and all(v > 0 for v in t.values())
+    assert set(t["traffic"]) == {"k_lsi", "k_pip"} and all(v > 0 for v in t["traffic"].values())
+    assert len(t["kernel_source_hash"]) == 16 and t["tag"].startswith("r")
+    for k in ("k_lsi", "k_pip"):
+        assert t["sq"][k]["SQ_ACTIVE_INST_VALU"] > 0 and t["sq"][k]["GRBM_GUI_ACTIVE"] > 0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "kernel_source_hash" in src and "stale" in src
