@@ -86,6 +86,15 @@ int rj_map_num_points(rj_handle h, int map_id, uint64_t* np);
 /* device pointer to the uploaded scaled points (int64 x,y pairs), owned by the handle */
 int rj_map_points_dev(rj_handle h, int map_id, const int64_t** pts_dev);
 
+/* replaces: Scaling(bb) + the scale pass of Map::LoadFrom (src/map/scaling.h:56-93, src/map/map.h:171-180)
+ * for hosts that do not scale themselves: xy[2n] doubles -> out_xy[2n] scaled int64, bb = {min_x, min_y,
+ * max_x, max_y} of BOTH maps (src/context.h:37-47).  Host code, no GPU involved.
+ * fused = 0: a separate multiply and add, what scaling.h spells out and what its host build computes
+ * (the arithmetic every parity test of this repository is pinned to); fused = 1: one std::fma, what
+ * nvcc's default -fmad=true makes of the same expression inside the reference's device lambda -- the
+ * two differ by one unit for about 0.14 % of points.  Use the same setting for both maps. */
+int rj_scale_points(const double bb[4], const double* xy, uint64_t n, int64_t* out_xy, int fused);
+
 /* ---- index ---------------------------------------------------------------------------- */
 /* replaces: FillPrimitivesLBVH + lbvh::bvh::assign/construct (src/tree/primtive.h:34-57,
  * deps/lbvh/lbvh/bvh.cuh:277-481) as called at src/run_query.cu:273-290,422-438. */

@@ -30,6 +30,7 @@ SYMBOLS = {
     "rj_last_error_string": (C.c_char_p, [_vp]),
     "rj_version": (C.c_char_p, []),
     "rj_upload_map": (_int, [_vp, _int, _vp, _u64, _vp, _vp, _vp, _u64]),
+    "rj_scale_points": (_int, [_vp, _vp, _u64, _vp, _int]),
     "rj_map_num_edges": (_int, [_vp, _int, C.POINTER(_u64)]),
     "rj_map_num_points": (_int, [_vp, _int, C.POINTER(_u64)]),
     "rj_map_points_dev": (_int, [_vp, _int, C.POINTER(_vp)]),
@@ -71,6 +72,18 @@ def kernel_source_hash():
         with open(os.path.join(HERE, "csrc", name), "rb") as f:
             hsh.update(f.read())
     return hsh.hexdigest()[:16]
+
+
+def scale_points(bb, xy, fused=False):
+    """rj_scale_points: Scaling(bb).ScaleX/ScaleY over xy (host code of the library, no GPU).
+    fused=True reproduces the FMA that nvcc contracts the reference's device lambda into."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+    b = np.ascontiguousarray(bb, dtype=np.float64)
+    out = np.empty(xy.shape, dtype=np.int64)
+    rc = load().rj_scale_points(b.ctypes.data, xy.ctypes.data, xy.shape[0], out.ctypes.data, int(bool(fused)))
+    if rc != RJ_OK:
+        raise RayJoinError(rc, "rj_scale_points failed")
+    return out
 
 
 class RayJoinError(RuntimeError):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -356,6 +357,31 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (rc) return rc;
   RJ_HIP(h, e);
   m.present = true;
+  return RJ_OK;
+}
+
+int rj_scale_points(const double bb[4], const double* xy, uint64_t n, int64_t* out_xy, int fused) {
+  if (!bb || (n && (!xy || !out_xy))) return RJ_E_INVALID;
+  // Scaling<double, int64_t, 17>(bb), src/map/scaling.h:43-72 (this file is built with -ffp-contract=off)
+  const int64_t imax = INT64_MAX >> 17, imin = INT64_MIN >> 17;
+  const double range = (double) (imax - imin);
+  const double max_x = bb[2] + 1, min_x = bb[0] - 1, max_y = bb[3] + 1, min_y = bb[1] - 1;  // SCALING_BOUNDING_BOX_MARGIN
+  const double rx = range / (max_x - min_x), ry = range / (max_y - min_y);
+  const double dx = 0.5 * ((imax + imin) - (max_x + min_x) * rx), dy = 0.5 * ((imax + imin) - (max_y + min_y) * ry);
+  for (uint64_t i = 0; i < n; i++) {
+    const double x = xy[2 * i], y = xy[2 * i + 1];
+    double sx, sy;
+    if (fused) {
+      sx = std::fma(x, rx, dx);
+      sy = std::fma(y, ry, dy);
+    } else {
+      const double tx = x * rx, ty = y * ry;
+      sx = tx + dx;
+      sy = ty + dy;
+    }
+    out_xy[2 * i] = (int64_t) sx;
+    out_xy[2 * i + 1] = (int64_t) sy;
+  }
   return RJ_OK;
 }
 

@@ -5,6 +5,7 @@
 // be compiled with -ffp-contract=off; SURVEY 7 hard part 7) and shipped to the GPU as int64.
 #pragma once
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <iostream>
 #include <memory>
@@ -20,7 +21,9 @@ namespace rayjoin {
 class Scaling {
  public:
   Scaling() = default;
-  explicit Scaling(const BoundingBox& bb) {
+  // fused: x * rx + delta as ONE std::fma -- what nvcc's default -fmad=true makes of the reference's
+  // device lambda (src/map/map.h:171-180); the default is scaling.h's separate multiply and add.
+  explicit Scaling(const BoundingBox& bb, bool fused = false) : fused_(fused) {
     double max_x = bb.max_x + 1, min_x = bb.min_x - 1, max_y = bb.max_y + 1, min_y = bb.min_y - 1;  // config.h:4
     rx_ = (double) internal_range_ / (max_x - min_x);
     ry_ = (double) internal_range_ / (max_y - min_y);
@@ -31,8 +34,8 @@ class Scaling {
     ddeltax_ = 0.5 * ((max_x + min_x) - (internal_max_ + internal_min_) * rrx_);
     ddeltay_ = 0.5 * ((max_y + min_y) - (internal_max_ + internal_min_) * rry_);
   }
-  int64_t ScaleX(double x) const { double t = x * rx_; return (int64_t) (t + deltax_); }
-  int64_t ScaleY(double y) const { double t = y * ry_; return (int64_t) (t + deltay_); }
+  int64_t ScaleX(double x) const { if (fused_) return (int64_t) std::fma(x, rx_, deltax_); double t = x * rx_; return (int64_t) (t + deltax_); }
+  int64_t ScaleY(double y) const { if (fused_) return (int64_t) std::fma(y, ry_, deltay_); double t = y * ry_; return (int64_t) (t + deltay_); }
   double UnscaleX(int64_t v) const { double t = (double) v * rrx_; return t + ddeltax_; }
   double UnscaleY(int64_t v) const { double t = (double) v * rry_; return t + ddeltay_; }
   int64_t get_internal_min() const { return internal_min_; }
@@ -43,6 +46,7 @@ class Scaling {
   int64_t internal_max_ = INT64_MAX >> 17, internal_min_ = INT64_MIN >> 17;
   int64_t internal_range_ = (INT64_MAX >> 17) - (INT64_MIN >> 17);
   double rx_ = 0, ry_ = 0, rrx_ = 0, rry_ = 0, deltax_ = 0, deltay_ = 0, ddeltax_ = 0, ddeltay_ = 0;
+  bool fused_ = false;
 };
 
 struct RjError : std::runtime_error {
@@ -106,13 +110,13 @@ class Stream {
 
 class Context {
  public:
-  explicit Context(const std::array<std::shared_ptr<PlanarGraph>, 2>& pgs, int device = 0) : pgraphs_(pgs) {
+  explicit Context(const std::array<std::shared_ptr<PlanarGraph>, 2>& pgs, int device = 0, bool fused_scaling = false) : pgraphs_(pgs) {
     for (auto& g : pgs)
       if (g) {
         bb_.min_x = std::min(bb_.min_x, g->bb.min_x); bb_.max_x = std::max(bb_.max_x, g->bb.max_x);
         bb_.min_y = std::min(bb_.min_y, g->bb.min_y); bb_.max_y = std::max(bb_.max_y, g->bb.max_y);
       }
-    scaling_ = Scaling(bb_);
+    scaling_ = Scaling(bb_, fused_scaling);
     std::cerr << "Bounding Box, Bottom-left: (" << bb_.min_x << ", " << bb_.min_y << "), Top-right: (" << bb_.max_x
               << ", " << bb_.max_y << ")" << std::endl;
     int rc = rj_create(device, &h_);

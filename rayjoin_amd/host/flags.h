@@ -27,6 +27,7 @@ struct Flags {
   int nranks = 1, rank = 0;  // ours: one process per GPU; the query map is sharded by chain range
   std::string comm_file;     // ours: rank 0 writes the RCCL unique id here, the others read it
   std::string sample_output; // ours: write the sampled map (-sample) as a .bin cache file, for inspection/tests
+  bool scale_fma = false;    // ours: scale with one fma per coordinate (nvcc's contraction of map.h:171-180) instead of scaling.h's multiply + add
 
   static bool parse_bool(const std::string& s) {
     if (s == "" || s == "1" || s == "true" || s == "t" || s == "yes" || s == "y") return true;
@@ -43,7 +44,7 @@ struct Flags {
     RJ_S(poly1) RJ_S(poly2) RJ_S(output) RJ_S(mode) RJ_S(serialize) RJ_S(sample) RJ_S(query)
     RJ_I(grid_size) RJ_D(xsect_factor) RJ_B(box) RJ_B(check) RJ_B(fau) RJ_I(warmup) RJ_I(repeat)
     RJ_I(ag) RJ_I(ag_iter) RJ_I(win) RJ_D(enlarge) RJ_I(sample_map_id) RJ_D(sample_rate)
-    RJ_I(seed) RJ_D(gen_t) RJ_I(gen_n) RJ_B(histo) RJ_B(profile) RJ_I(v) RJ_I(device) RJ_I(nranks) RJ_I(rank) RJ_S(comm_file) RJ_S(sample_output)
+    RJ_I(seed) RJ_D(gen_t) RJ_I(gen_n) RJ_B(histo) RJ_B(profile) RJ_B(scale_fma) RJ_I(v) RJ_I(device) RJ_I(nranks) RJ_I(rank) RJ_S(comm_file) RJ_S(sample_output)
 #undef RJ_S
 #undef RJ_I
 #undef RJ_D
@@ -53,7 +54,7 @@ struct Flags {
   }
 
   static bool is_bool(const std::string& k) {
-    static const char* b[] = {"box", "check", "fau", "histo", "profile"};
+    static const char* b[] = {"box", "check", "fau", "histo", "profile", "scale_fma"};
     for (auto n : b) if (k == n || k == std::string("no") + n) return true;
     return false;
   }

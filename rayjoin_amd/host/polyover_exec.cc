@@ -138,7 +138,7 @@ void RunOverlay(const Flags& f) {  // run_overlay.cu:143-228
   tm.next("Read map 1");
   auto g2 = load_from(f.poly2, f.serialize, f.v);
   tm.next("Create App");
-  Context ctx({g1, g2}, f.device);
+  Context ctx({g1, g2}, f.device, f.scale_fma);
   MapOverlayLBVH overlay(ctx, f.xsect_factor, f.mode == "grid", f.grid_size);
   tm.next("Load Data");
   ctx.LoadToDevice();

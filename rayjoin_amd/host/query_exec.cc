@@ -180,13 +180,13 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
   if (f.poly2.empty()) {
     ApplySampling(f, base, nullptr);
     tm.next("Generate Workloads");
-    ctx.reset(new Context({base, nullptr}, f.device));
+    ctx.reset(new Context({base, nullptr}, f.device, f.scale_fma));
     gen_queries = GenerateLSIQueries(f, *ctx);
   } else {
     tm.next("Read map 1");
     auto query = load_from(f.poly2, f.serialize, f.v);
     ApplySampling(f, base, &query);
-    ctx.reset(new Context({base, query}, f.device));
+    ctx.reset(new Context({base, query}, f.device, f.scale_fma));
   }
   tm.next("Create App");
   const bool grid = f.mode == "grid";
@@ -258,7 +258,7 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   if (f.poly2.empty()) {
     ApplySampling(f, base, nullptr);
     tm.next("Generate Workloads");
-    ctx.reset(new Context({base, nullptr}, f.device));
+    ctx.reset(new Context({base, nullptr}, f.device, f.scale_fma));
     gen_pts = GeneratePIPQueries(f, *ctx);
     tm.next("Load Data");
     ctx->LoadToDevice();
@@ -269,7 +269,7 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
     tm.next("Read map 1");
     auto query = load_from(f.poly2, f.serialize, f.v);
     ApplySampling(f, base, &query);
-    ctx.reset(new Context({base, query}, f.device));
+    ctx.reset(new Context({base, query}, f.device, f.scale_fma));
     tm.next("Load Data");
     ctx->LoadToDevice();
     n_points = ctx->get_map(1)->n_points();

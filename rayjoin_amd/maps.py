@@ -202,7 +202,12 @@ def sample_edges_from(g, sample_rate, seed=0):
 class Scaling:
     """Scaling<double, int64_t, 17> (scaling.h:32-136)."""
 
-    def __init__(self, bb):
+    def __init__(self, bb, fused=False):
+        """fused=True: scale() computes x*rx + dx as ONE fma, what nvcc makes of the reference's
+        device lambda (src/map/map.h:171-180); the default is the separate multiply and add that
+        scaling.h spells out and its host build computes."""
+        self.bb = tuple(float(v) for v in bb)
+        self.fused = bool(fused)
         min_x, min_y, max_x, max_y = (np.float64(v) for v in bb)
         m = np.float64(SCALING_BOUNDING_BOX_MARGIN)
         mxx, mnx, mxy, mny = max_x + m, min_x - m, max_y + m, min_y - m
@@ -219,6 +224,9 @@ class Scaling:
 
     def scale(self, xy):
         xy = np.asarray(xy, dtype=np.float64).reshape(-1, 2)
+        if self.fused:  # numpy has no fma: the library's host helper does it (std::fma)
+            from . import _capi
+            return _capi.scale_points(self.bb, xy, fused=True)
         out = np.empty(xy.shape, dtype=np.int64)
         # separate multiply and add (numpy never fuses), C-style truncation toward zero
         out[:, 0] = (xy[:, 0] * self.rx + self.dx).astype(np.int64)
@@ -301,7 +309,7 @@ class ScaledMap:
 class Context:
     """src/context.h:31-88: owns the (up to) two planar graphs, the joint bbox and the scaling."""
 
-    def __init__(self, pgraphs):
+    def __init__(self, pgraphs, fused_scaling=False):
         if isinstance(pgraphs, PlanarGraph):
             pgraphs = [pgraphs, None]
         self.planar_graphs = list(pgraphs) + [None] * (2 - len(pgraphs))
@@ -312,7 +320,7 @@ class Context:
                 bb = [min(bb[0], g.bb[0]), min(bb[1], g.bb[1]), max(bb[2], g.bb[2]), max(bb[3], g.bb[3])]
         self.bb = tuple(bb)
         # no planar graph (maps injected later through set_map / .maps): leave the scaling unset
-        self.scaling = Scaling(self.bb) if any(g is not None for g in self.planar_graphs) else None
+        self.scaling = Scaling(self.bb, fused_scaling) if any(g is not None for g in self.planar_graphs) else None
         self.maps = [None, None]
 
     def load(self):
