@@ -7,9 +7,9 @@
  * links, includes or calls anything in this directory.
  *
  * Parity pin: the predicate-level functions (intersect_test, intersection point,
- * rational arithmetic, calculate_cell) are checked against vectors produced by the
- * reference's own headers compiled on the host (oracle/ref/, tests/golden/lsi_ref_vectors.json)
- * and against the known answers recorded in SURVEY.md 8c.  The PIP predicate and all
+ * rational arithmetic, calculate_cell) and Scaling are checked against vectors produced by the
+ * reference's own headers compiled on the host (oracle/ref/, tests/golden/lsi_ref_vectors.json,
+ * tests/golden/scaling_ref_vectors.json) and against the known answers recorded in SURVEY.md 8c.  The PIP predicate and all
  * dataset-level behaviour have no reference-owned fixture (the test/dataset files are missing from
  * the snapshot): for those rows parity is UNPINNED by the reference and rests on this
  * restatement cross-checked by brute force (see DESIGN.md "Oracle").
