@@ -101,18 +101,20 @@ def test_four_level_tree_parity(oracle):
     h.close()
 
 
-def test_lakes_parks_pip_full_base(oracle):
-    """BASELINE.json configs[2] (Lakes x Parks, -query=pip) with the base map at FULL size
-    (66.9 M segments, 1.05 M leaf blocks): every 13th vertex of the Parks stand-in (2.1 M points)
-    against the oracle's grid PIP, bit-exact eids and face ids."""
+def test_lakes_parks_pip_full_size(oracle):
+    """BASELINE.json configs[2] (Lakes x Parks, -query=pip) at FULL size: the 66.9 M-segment base map
+    (1.05 M leaf blocks, 4 levels) and EVERY vertex of the Parks stand-in (27.8 M points) against the
+    oracle's grid PIP, bit-exact eids and face ids.  (With less host memory than the oracle's grid
+    needs: every 13th vertex.)"""
     import psutil
-    if psutil.virtual_memory().available < 40 << 30:
+    avail = psutil.virtual_memory().available
+    if avail < 40 << 30:
         pytest.skip("needs ~30 GB of host memory for the 66.9 M-segment map and the oracle's grid")
     oracle.lib().rjo_set_num_threads(16)
     ctx = maps.Context([synth.standin("LakesNA"), synth.standin("ParksNA")]).load()
     base, query = ctx.maps
     assert base.n_edges > 66_000_000
-    pts = np.ascontiguousarray(query.pts[::13])
+    pts = np.ascontiguousarray(query.pts if avail > (60 << 30) else query.pts[::13])
     h = _capi.Handle(0)
     h.upload_map(0, base.pts, base.row_index, base.left, base.right)
     h.build_lbvh(0)
@@ -126,6 +128,45 @@ def test_lakes_parks_pip_full_base(oracle):
     assert (eids != 0xFFFFFFFF).sum() > len(pts) // 2
     assert np.array_equal(we, eids)
     assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
+    h.close()
+
+
+def test_waterbodies_blockgroup_lsi_full_size_and_8_shards(oracle):
+    """BASELINE.json configs[4] (WaterBodies x BlockGroup LSI, query map sharded 8-way) on one GPU:
+    the whole join (24.4 M x 28.8 M segments, 4-level tree) bit-exact against the oracle's grid --
+    pairs and stored points -- and the 8 chain-range shards of the query map, queried one after the
+    other, reproduce it exactly (what the 8 ranks of the real run compute, minus the exchange)."""
+    import psutil
+    if psutil.virtual_memory().available < 40 << 30:
+        pytest.skip("needs ~25 GB of host memory for the two maps and the oracle's grid")
+    oracle.lib().rjo_set_num_threads(16)
+    ctx = maps.Context([synth.standin("WaterBodies"), synth.standin("BlockGroup")]).load()
+    base, query = ctx.maps
+    h = _capi.Handle(0)
+    h.upload_map(0, base.pts, base.row_index, base.left, base.right)
+    h.upload_map(1, query.pts, query.row_index, query.left, query.right)
+    h.build_lbvh(0)
+    cap = int(0.1 * (base.n_edges + query.n_edges))
+    pairs = h.alloc(8 * cap)
+    n = h.lsi_query(0, 1, 0, query.n_edges, cap, pairs)
+    h.sort_pairs(pairs, n)
+    got = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
+    xs_dev = h.alloc(48 * n)
+    h.lsi_points(pairs, n, xs_dev)
+    xs = xs_dev.to_host(_capi.XSECT_DTYPE, n)
+    m0 = oracle.Map(base.pts, base.row_index, base.left, base.right)
+    m1 = oracle.Map(query.pts, query.row_index, query.left, query.right)
+    want = oracle.lsi_grid(m0, m1, 4096, cap=cap)
+    assert len(want) == n > 1_000_000
+    assert np.array_equal(want["eid"], got)
+    assert np.array_equal(want["x_num"], xs["x_num"]) and np.array_equal(want["y_num"], xs["y_num"])
+    del m0, m1, want
+    parts = []
+    for c0, c1 in query.shard_chain_ranges(8):
+        e0, e1 = query.chain_range_to_eids(c0, c1)
+        k = h.lsi_query(0, 1, e0, e1, cap, pairs)
+        parts.append(pairs.to_host(np.uint32, 2 * k).reshape(-1, 2))
+    assert np.array_equal(oracle.sort_pairs(np.concatenate(parts)), got)
     h.close()
 
 
