@@ -87,6 +87,9 @@ struct rj_handle_s {
   bool last_ordered = false;
   // coherence decisions for map-owned query sets (immutable after upload): [kind 0=segs,1=points][map]
   struct CohCache { bool valid = false; uint64_t begin = 0, n = 0; bool incoherent = false; } coh[2][2];
+  // ... and the Morton permutation of such a set, kept until the map is uploaded again: repeated
+  // queries over the same immutable edges / vertices sort once (an index on the query side)
+  struct OrdCache { uint32_t* perm = nullptr; uint64_t cap = 0, begin = 0, n = 0; bool valid = false; } ordc[2][2];
   // grow-only scratch of the query-ordering pass
   uint64_t ord_cap = 0;
   MortonKey *ord_kin = nullptr, *ord_kout = nullptr;
@@ -239,6 +242,7 @@ int rj_destroy(rj_handle h) {
   (void) hipStreamSynchronize(h->stream);
   (void) hipStreamSynchronize(h->aux_stream);
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
+  for (int k = 0; k < 2; k++) for (int i = 0; i < 2; i++) (void) hipFree(h->ordc[k][i].perm);
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
@@ -328,6 +332,7 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   free_bvh(h->bvh[map_id]);
   free_grid(h->grid[map_id]);
   h->coh[0][map_id].valid = h->coh[1][map_id].valid = false;
+  h->ordc[0][map_id].valid = h->ordc[1][map_id].valid = false;
   m.np = np; m.nc = nc; m.ne = np - nc;
   std::vector<uint32_t> eb(nc + 1), l32(nc), r32(nc);
   for (uint64_t c = 0; c <= nc; c++) eb[c] = nc ? (uint32_t) (row_index[c] - c) : 0;
@@ -535,6 +540,12 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
     }
     if (!incoherent) return RJ_OK;
   }
+  rj_handle_s::OrdCache* oc = owner_map >= 0 ? &h->ordc[points ? 1 : 0][owner_map] : nullptr;
+  if (oc && oc->valid && oc->begin == key_begin && oc->n == n) {  // sorted before, the map has not changed
+    *order_out = oc->perm;
+    h->last_ordered = true;
+    return RJ_OK;
+  }
   if (int r = ensure_sort_scratch(h, n)) return r;
   tic(h, RJ_T_ORDER);
   RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin));
@@ -543,6 +554,18 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
   toc(h, RJ_T_ORDER);
   *order_out = h->ord_vout;
   h->last_ordered = true;
+  if (oc) {  // keep it (the sort scratch is shared with the index build and other queries)
+    oc->valid = false;
+    if (oc->cap < n) {
+      (void) hipFree(oc->perm);
+      oc->perm = nullptr; oc->cap = 0;
+      if (hipMalloc((void**) &oc->perm, n * sizeof(uint32_t)) != hipSuccess) { oc->perm = nullptr; return RJ_OK; }  // no cache, still correct
+      oc->cap = n;
+    }
+    RJ_HIP(h, hipMemcpyAsync(oc->perm, h->ord_vout, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+    oc->begin = key_begin; oc->n = n; oc->valid = true;
+    *order_out = oc->perm;
+  }
   return RJ_OK;
 }
 
