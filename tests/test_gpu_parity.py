@@ -345,3 +345,36 @@ def test_domain_spanning_segments(oracle):
     pip.Query(1, query_points=pts)
     assert np.array_equal(pip.get_closest_eids(), oracle.pip_brute(o0, 1, pts))
     dctx.close()
+
+
+def test_async_query_leaves_complete_records(oracle, lattice_pair):
+    """rj_lsi_query_async + rj_lsi_points_async + rj_lsi_query_finish: the 48-byte Intersection records
+    of the query are produced behind it on the stream (count read on the device) -- what
+    LSILBVH::Query leaves in its queue (src/app/lsi_lbvh.h:71-78) -- and equal the oracle's."""
+    ctx, dctx = lattice_pair
+    h = dctx.handle
+    m0, m1 = _omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1])
+    want = oracle.lsi_grid(m0, m1, 512)
+    cap = 3 * len(want)
+    pairs = h.alloc(8 * cap)
+    recs = h.alloc(48 * cap)
+    for _ in range(2):
+        h.lsi_query_async(0, 1, 0, ctx.maps[1].n_edges, cap, pairs)
+        h.lsi_points_async(pairs, cap, recs)
+        n = h.lsi_query_finish(cap)
+        assert n == len(want)
+        got = recs.to_host(_capi.XSECT_DTYPE, n)
+        key = (got["eid"][:, 0].astype(np.uint64) << np.uint64(32)) | got["eid"][:, 1]
+        got = got[np.argsort(key, kind="stable")]
+        for f in ("x_num", "x_den", "y_num", "y_den", "eid", "mid_point_polygon_id"):
+            assert np.array_equal(got[f], want[f]), f
+    # a capacity smaller than the result: the first `capacity` records are produced, the overflow is reported
+    small = 16
+    with pytest.raises(_capi.QueueOverflow) as ei:
+        h.lsi_query_async(0, 1, 0, ctx.maps[1].n_edges, small, pairs)
+        h.lsi_points_async(pairs, small, recs)
+        h.lsi_query_finish(small)
+    assert ei.value.n_found == len(want)
+    got = recs.to_host(_capi.XSECT_DTYPE, small)
+    ref = oracle.lsi_points(m0, m1, np.ascontiguousarray(got["eid"]))
+    assert np.array_equal(got["x_num"], ref["x_num"]) and np.array_equal(got["y_num"], ref["y_num"])
