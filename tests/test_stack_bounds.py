@@ -64,13 +64,15 @@ def test_stack_capacities_cover_the_worst_case(top):
 
 
 def test_lds_budget_keeps_the_occupancy():
-    """k_lsi: stack + 2 x 128 pair buffers per wave; k_pip: 16-byte entries + candidate lists.
+    """k_lsi: stack + 2 x 128 pair buffers per wave; k_pip: 16-byte entries + candidate lists
+    (+ the block's four 8-byte chunk ranges).
     160 KiB per CU must hold 7 (k_lsi) and 6 (k_pip) four-wave blocks -- the register-limited
     occupancies in DESIGN.md."""
     c = _consts()
     src = open(os.path.join(os.path.dirname(HDR), "rj_kernels.hip")).read()
     plist = int(re.search(r"constexpr int kPipList = (\d+);", src).group(1))
     lsi_block = 4 * (4 * c["kStackEntries"] + 2 * 128 * 8)
-    pip_block = 4 * (16 * c["kPipStack"] + plist * 64 * 4)
+    pip_block = 4 * (16 * c["kPipStack"] + plist * 64 * 4) + 4 * 8
+    assert "__shared__ unsigned long long ranges[4];" in src
     assert 7 * lsi_block <= 160 * 1024
     assert 6 * pip_block <= 160 * 1024
