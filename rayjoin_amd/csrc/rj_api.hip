@@ -97,7 +97,7 @@ struct rj_handle_s {
   void* ord_temp = nullptr;
   size_t ord_temp_bytes = 0;
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
-  int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (8 for both: measured optima; k_pip's waves share a chunk's rest inside the block)
+  int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
   int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
   uint64_t last_stats[16] = {0};
   // grow-only arena for the overlay pass (carved per call, no per-call hipMalloc/hipFree)
@@ -729,7 +729,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.query_map_id = query_map_id;
   a.closest = closest_eid_dev; a.face = face_id_dev;
   a.work_counter = (unsigned int*) sched;
-  a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 8);
+  a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 6);
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
