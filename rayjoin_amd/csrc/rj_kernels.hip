@@ -389,7 +389,7 @@ __device__ __forceinline__ bool next_chunk(unsigned int* counters, uint32_t nchu
 
 // Group-by-group hand-out on top of next_chunk, with stealing inside the block (k_pip).  A wave
 // walks its chunk in order (the next group re-hits what the last one loaded), but the chunk's
-// unstarted rest is visible to the block's other three waves in LDS -- {end : next} per wave, a
+// unstarted rest is visible to the block's other waves in LDS -- {end : next} per wave, a
 // group is claimed with one ds_add_rtn_u64 by owner and thief alike.  When the global queue is dry,
 // a wave without work takes single groups from a sibling that still holds some: the kernel's tail
 // is a group, not a chunk, per block.  Measured with tools/timeline: with
@@ -403,6 +403,7 @@ __device__ __forceinline__ bool take_from(unsigned long long* range, int lane, u
   g = nx;
   return nx < en;
 }
+template <int NWAVES>
 __device__ __forceinline__ bool next_group(unsigned long long* ranges, int wib, unsigned int* counters, uint32_t nchunks,
                                            uint32_t chunk_groups, uint64_t ngroups, int& part, int& tried, int lane, uint32_t& g) {
   if (take_from(&ranges[wib], lane, g)) return true;
@@ -417,8 +418,10 @@ __device__ __forceinline__ bool next_group(unsigned long long* ranges, int wib, 
     return true;
   }
   // the global queue is dry for good (tried == 8): help a sibling out
-  for (int s = 1; s < 4; s++)
-    if (take_from(&ranges[(wib + s) & 3], lane, g)) return true;
+  for (int s = 1; s < NWAVES; s++) {
+    const int w = wib + s < NWAVES ? wib + s : wib + s - NWAVES;
+    if (take_from(&ranges[w], lane, g)) return true;
+  }
   return false;
 }
 
@@ -786,6 +789,10 @@ __global__ __launch_bounds__(256) void k_swap_halves(uint64_t* __restrict__ v, u
 //     products, and the slope only on ties.
 // =============================================================================================
 constexpr int kPipList = 6;     // candidate slots per lane between two exact-evaluation rounds
+#ifndef RJ_PIP_WAVES
+#define RJ_PIP_WAVES 4
+#endif
+constexpr int kPipWaves = RJ_PIP_WAVES;  // waves per block = the waves that share their chunks' rests (next_group)
 constexpr int kPipRefineAbove = 16;  // per-lane check at push time only when more children than this pass the group test
 // (kPipStack: rj_device.h -- 16-byte entries; with the lists, 6656 B per wave = 6 blocks per CU)
 
@@ -797,8 +804,8 @@ struct PipWaveLds {
 };
 
 template <bool STATS>
-__global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
-  __shared__ PipWaveLds lds[4];
+__global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
+  __shared__ PipWaveLds lds[kPipWaves];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   PipWaveLds& L = lds[wib];
@@ -814,14 +821,14 @@ __global__ __launch_bounds__(256, 6) void k_pip(PipArgs A) {
 
   const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
   int part = blockIdx.x & 7, tried = 0;
-  __shared__ unsigned long long ranges[4];  // per wave {end : next}: the unstarted rest of its chunk
-  if (threadIdx.x < 4) ranges[threadIdx.x] = 0;
+  __shared__ unsigned long long ranges[kPipWaves];  // per wave {end : next}: the unstarted rest of its chunk
+  if (threadIdx.x < kPipWaves) ranges[threadIdx.x] = 0;
   __syncthreads();
   for (;;) {  // XCD-aware dynamic chunked scheduling, see next_chunk / next_group
   {
     uint32_t g32 = 0;
     const long long tks = STATS ? clock64() : 0;
-    if (!next_group(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
+    if (!next_group<kPipWaves>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
     if (STATS) tk_sched += clock64() - tks;
     const uint64_t g = g32;
     const long long tkg = STATS ? clock64() : 0;
@@ -1138,11 +1145,11 @@ hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_chi
   return hipGetLastError();
 }
 
-static int resident_blocks(const void* kernel, int max_blocks) {
+static int resident_blocks(const void* kernel, int max_blocks, int block_threads = 256) {
   int dev = 0, cus = 256, per_cu = 4;
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block_threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
   int b = cus * per_cu;
   return b < max_blocks ? b : max_blocks;
 }
@@ -1150,8 +1157,8 @@ static int resident_blocks(const void* kernel, int max_blocks) {
 // Small query sets: with 64 queries per wave there are fewer groups than resident waves and each
 // wave walks a long serial chain of node visits.  Fewer queries per wave spread the same visits
 // over more waves (the kernels are latency-bound, idle lanes cost nothing).
-static uint32_t pick_group_lanes(uint64_t nqueries, int resident_blocks_) {
-  const uint64_t waves = (uint64_t) resident_blocks_ * 4;
+static uint32_t pick_group_lanes(uint64_t nqueries, int resident_blocks_, int block_waves = 4) {
+  const uint64_t waves = (uint64_t) resident_blocks_ * block_waves;
   uint32_t gl = 64;
   while (gl > 4 && (nqueries + gl - 1) / gl < 2 * waves) gl >>= 1;
   return gl;
@@ -1216,15 +1223,15 @@ hipError_t launch_pip(hipStream_t st, const PipArgs& a_in, bool stats, int max_b
   PipArgs a = a_in;
   const void* k = stats ? (const void*) k_pip<true> : (const void*) k_pip<false>;
   static int res[2] = {0, 0};
-  if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
-  if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.n, res[stats]);
+  if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20, 64 * kPipWaves);
+  if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.n, res[stats], kPipWaves);
   uint64_t ngroups = (a.n + a.group_lanes - 1) / a.group_lanes;
   uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
-  int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
+  int grid = grid_for(nchunks, kPipWaves, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
-    hipLaunchKernelGGL(k_pip<true>, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pip<true>, dim3(grid), dim3(64 * kPipWaves), 0, st, a);
   else
-    hipLaunchKernelGGL(k_pip<false>, dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_pip<false>, dim3(grid), dim3(64 * kPipWaves), 0, st, a);
   return hipGetLastError();
 }
 

@@ -73,6 +73,7 @@ def test_lds_budget_keeps_the_occupancy():
     plist = int(re.search(r"constexpr int kPipList = (\d+);", src).group(1))
     lsi_block = 4 * (4 * c["kStackEntries"] + 2 * 128 * 8)
     pip_block = 4 * (16 * c["kPipStack"] + plist * 64 * 4) + 4 * 8
-    assert "__shared__ unsigned long long ranges[4];" in src
+    waves = int(re.search(r"#define RJ_PIP_WAVES (\d+)", src).group(1))
+    assert waves == 4 and "__shared__ unsigned long long ranges[kPipWaves];" in src
     assert 7 * lsi_block <= 160 * 1024
     assert 6 * pip_block <= 160 * 1024

@@ -41,15 +41,21 @@ def patch_kernel(k, name, light, group_tail_old, group_tail_new):
                    "  const long long tk_begin = STATS ? clock64() : 0;\n"
                    "  const unsigned long long tl_t0 = wall_clock64();\n"
                    "  unsigned long long tl_first = 0, tl_n = 0, tl_sched = 0, tl_last = 0;\n")
-        body = sub(body, "  if (!next_chunk(A.work_counter, nchunks, part, tried, lane, chunk)) break;\n",
-                   "  const unsigned long long tl_s0 = wall_clock64();\n"
-                   "  const bool tl_ok = next_chunk(A.work_counter, nchunks, part, tried, lane, chunk);\n"
-                   "  tl_sched += wall_clock64() - tl_s0;\n"
-                   "  if (!tl_ok) break;\n"
-                   "  if (!tl_first) tl_first = wall_clock64();\n")
+    # the scheduler call and the start of a group's work (k_lsi: next_chunk + a loop over the chunk;
+    # k_pip: next_group hands out one group at a time)
+    if name == "k_lsi":
+        body = sub(body, "  for (uint64_t g = g_begin; g < g_end; g++) {\n", "  for (uint64_t g = g_begin; g < g_end; g++) {\n@START@")
+    else:
+        call = "    if (!next_group(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;\n"
+        body = sub(body, call,
+                   "    const unsigned long long tl_s0 = wall_clock64();\n"
+                   "    const bool tl_ok = next_group(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32);\n"
+                   "    tl_sched += wall_clock64() - tl_s0;\n"
+                   "    if (!tl_ok) break;\n"
+                   "    if (!tl_first) tl_first = wall_clock64();\n")
+        body = sub(body, "    const uint64_t g = g32;\n", "    const uint64_t g = g32;\n@START@")
     # (no value lives across the group body: the start goes to memory at once)
-    body = sub(body, "  for (uint64_t g = g_begin; g < g_end; g++) {\n",
-               "  for (uint64_t g = g_begin; g < g_end; g++) {\n"
+    body = sub(body, "@START@",
                "    if (!STATS && lane == 0 && g < %dull) {\n"
                "      unsigned long long* tl = *reinterpret_cast<unsigned long long* const*>(A.work_counter + kSchedFaultPtrWord + 2);\n"
                "      if (tl) tl[8 * %d + 2 * g] = wall_clock64();\n"
