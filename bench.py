@@ -38,7 +38,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)    # the reference's -repeat=5
-    ap.add_argument("--warmup", type=int, default=5)   # the reference's -warmup=5
+    ap.add_argument("--warmup", type=int, default=8)   # (the reference: -warmup=5; the first six steps also pick the kernel schedule)
     ap.add_argument("--base", default="USCounty")
     ap.add_argument("--query", default="BlockGroup")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink both stand-ins (debug only)")
@@ -141,7 +141,9 @@ def main():
     h.build_lbvh(0)
     h.build_lbvh(0)  # second build = steady-state allocator
     if not args.serial_kernels:
-        h.set_option("pip_concurrent", 2)  # LSI and PIP of a step are independent: small shards let them overlap
+        # LSI and PIP of a step are independent: "auto" tries them one after the other, sharing the chip and beside
+        # each other on full grids during the first six steps and keeps the fastest schedule (include/rayjoin_amd.h)
+        h.set_option("pip_concurrent", 2)
     build_ms = h.last_ms(_capi.RJ_T_BUILD)
 
     # ---- shard the query map by chain range -------------------------------------
@@ -207,6 +209,7 @@ def main():
     else:
         n_x = state["n"]
     ms_per_step = elapsed * 1e3 / args.steps
+    schedule = h.get_option("pip_schedule")
 
     # order-independent digest of the step's results, summed over ranks (untimed): lets a test compare
     # an N-rank run with the single-GPU run of the same workload without shipping the results
@@ -233,7 +236,9 @@ def main():
 
     # phase split (synchronous calls, wall clock), one extra untimed pass
     t0 = time.perf_counter(); h.lsi_query(0, 1, e0, e1, cap, pairs); t_lsi_wall = time.perf_counter() - t0
+    lsi_alone_ms = h.last_ms(_capi.RJ_T_LSI_KERNEL)  # (a synchronous query: the kernel has the chip to itself)
     t0 = time.perf_counter(); h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); t_pip_wall = time.perf_counter() - t0
+    pip_alone_ms = h.last_ms(_capi.RJ_T_PIP_KERNEL)
 
     checks = None
     if args.check and rank == 0 and world == 1:
@@ -273,7 +278,15 @@ def main():
                     roof[name]["salu_busy_frac"] = round(c["SQ_ACTIVE_INST_SCA"] / avail, 3)
                 if roof[name]["valu_busy_frac"] > 0.6:
                     roof[name]["limiter"] = "valu-issue"
+        if schedule in (1, 2):
+            # the two kernels ran BESIDE each other in the timed steps: a kernel's duration there is not what it
+            # needs alone, and the durations add up to more than the step -- say so, and add the solo figures
+            for name, b, alone in (("lsi", b_lsi, lsi_alone_ms), ("pip", b_pip, pip_alone_ms)):
+                roof[name]["concurrent_with"] = "k_pip" if name == "lsi" else "k_lsi"
+                roof[name]["kernel_ms_alone"] = round(alone, 4)
+                roof[name]["frac_alone"] = round(b / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         dom = "lsi" if lsi_k >= pip_k else "pip"
+        b_step = b_lsi + b_pip + 56 * state["n"]  # + the 48-byte records and the pairs read back for them
         out = {
             "metric": "LSI+PIP query throughput, %s |><| %s" % (args.base, args.query),
             "value": round(n_s / (ms_per_step * 1e-3) / 1e6, 3), "unit": "M query segments/s",
@@ -286,7 +299,11 @@ def main():
                                     % (world, " and PIP eids" if args.gather_pip else "; PIP results stay with their shard"))
                                    if world > 1 else ("single GPU" if not args.emulate_shard else
                                                       "DIAGNOSTIC: rank 0's shard of a %d-way run on one GPU, value is NOT a job throughput" % args.emulate_shard),
-                       "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale},
+                       "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale,
+                       # what rj_set_option("pip_concurrent", 2) settled on for this workload (rank 0)
+                       "kernel_schedule": {1: "k_lsi and k_pip share the chip (1.25 + 5 blocks per CU)", 0: "k_lsi, then k_pip",
+                                           2: "k_lsi and k_pip beside each other, each on its full grid",
+                                           -1: "undecided (fewer than 7 paired steps)"}[schedule]},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
             "pip_mpoints_per_s": round(n_p / max(t_pip_wall, 1e-9) / 1e6, 2) if world == 1 else None,
@@ -294,6 +311,9 @@ def main():
             "intersections": n_x, "build_index_ms": round(build_ms, 3),
             "host_ms": {"generate": round(t_gen * 1e3, 1), "upload_and_segment_build": round(t_upload * 1e3, 1)},
             "roofline": roof[dom], "roofline_other": roof["pip" if dom == "lsi" else "lsi"],
+            # the whole step against the same roofline: all algorithmic bytes of the step over the step's time
+            "roofline_step": {"bound": "hbm", "achieved": round(b_step / (ms_per_step * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(b_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_step},
         }
         if checks is not None:
             out["checks"] = checks

@@ -222,16 +222,26 @@ int rj_last_ms(rj_handle h, int which, float* ms);
  * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
 int rj_last_stats(rj_handle h, uint64_t stats[16]);
 /* options: "stats" 0/1 (instrumented kernels); "chunk_groups" n (consecutive groups handed to a
- * wave at a time; 0 = automatic, the default: 8 for LSI, 4 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
+ * wave at a time; 0 = automatic, the default: 8 for LSI, 6 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
  * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
  * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
  * consecutive queries are spatially scattered, e.g. the generated workloads of
- * src/run_query.cu:102-167) / 2 always.   "pip_concurrent" 0 never (default) / 1 always / 2 auto (only for
- * query sets small enough to leave the chip partly idle): rj_pip_query_async launches on a second
- * stream owned by the handle, so the PIP kernel overlaps work on the main stream (the LSI kernel of
- * the same step: both only read the maps and the index).  Its inputs must be complete when the call
+ * src/run_query.cu:102-167) / 2 always.   "pip_concurrent" 0 never (default) / 1 always /
+ * 2 auto: the caller issues rj_lsi_query_async and rj_pip_query_async in PAIRS (the step of a join:
+ * both only read the maps and the index) and the two kernels may run beside each other instead of
+ * taking turns: with 1 the LSI kernel runs on 1.25 blocks per compute unit and the PIP kernel, on a
+ * second stream owned by the handle, on 5.  That is faster on some workloads and slower on others,
+ * so "auto" runs the first six pairs in three ways (taking turns / sharing the chip as above / beside
+ * each other on full grids), keeps the fastest, and decides again when the index, a map or the query
+ * size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
+ * rj_lsi_query and a PIP query without an LSI query in flight always use the whole chip.)  The PIP
+ * query's inputs must be complete when the call
  * is made; its outputs are complete after rj_sync, rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL). */
 int rj_set_option(rj_handle h, const char* name, int64_t value);
+/* current value of an option of rj_set_option; additionally "pip_schedule": what "pip_concurrent" 2 has
+ * decided for the current workload (0 taking turns, 1 sharing the chip, 2 beside each other on full grids,
+ * -1 still trying) and "pip_schedule_trials": the pairs it has measured so far. */
+int rj_get_option(rj_handle h, const char* name, int64_t* value);
 
 /* ---- device memory helpers (for hosts without their own allocator) -------------------- */
 int rj_dev_alloc(rj_handle h, size_t bytes, void** out_dev);

@@ -56,6 +56,7 @@ SYMBOLS = {
     "rj_last_ms": (_int, [_vp, _int, C.POINTER(C.c_float)]),
     "rj_last_stats": (_int, [_vp, C.POINTER(_u64)]),
     "rj_set_option": (_int, [_vp, C.c_char_p, _i64]),
+    "rj_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "rj_dev_alloc": (_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rj_dev_free": (_int, [_vp, _vp]),
     "rj_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -205,6 +206,11 @@ class Handle:
 
     def set_option(self, name, value):
         self._check(self.L.rj_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = _i64()
+        self._check(self.L.rj_get_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)

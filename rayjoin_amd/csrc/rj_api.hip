@@ -64,7 +64,24 @@ struct rj_handle_s {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t aux_stream = nullptr;  // "pip_concurrent": PIP launches go here so that they overlap the LSI kernel
-  int pip_concurrent = 0;  // 0 never, 1 always, 2 auto (small query sets only)
+  int pip_concurrent = 0;  // 0 never; 1: the caller issues LSI and PIP queries in pairs and they share the chip; 2: auto (see co_* below)
+  int cus = 256;           // compute units of the device
+  bool lsi_inflight = false;  // an asynchronous LSI query was launched and not yet finished / synced
+  bool lsi_shared = false;    // ... on a reduced grid, waiting for its PIP partner
+  // "pip_concurrent" 2: three schedules for an LSI + PIP pair -- 0: one after the other on the main
+  // stream; 1: beside each other on shared grids (k_lsi 1.25 blocks per CU, k_pip 5); 2: beside each
+  // other, each on its own full grid (whichever starts first fills the chip, the other fills its
+  // ramp and tail).  Which one wins depends on the workload (headline pair: 1 by 9 %; 24-67 M-segment
+  // trees: 0 by 35 % over 1; a 1/8 shard against the 24 M-segment tree: 2), so the first pairs run
+  // 0, 1, 2, 0, 1, 2 and the fastest is kept until the index, the maps or the query size change.
+  // The span of a pair = start of its LSI kernel .. end of the last of k_lsi, k_lsi_points, k_pip.
+  int co_trials = 0;          // pairs measured so far
+  float co_best[3] = {1e30f, 1e30f, 1e30f};  // best span [ms] per schedule
+  int co_choice = -1;         // decided schedule, -1 while trying
+  int co_mode = 0;            // schedule of the pair in flight
+  bool co_measure = false;    // the pair in flight is complete (LSI + PIP): its span can be read
+  bool co_points = false;     // ... and k_lsi_points ran between them
+  uint64_t co_n = 0;          // query size the decision was made for
   bool aux_pending = false;          // something was enqueued on aux_stream since it was last joined
   hipStream_t stream = nullptr;
   MapState map[2];
@@ -184,6 +201,33 @@ hipError_t join_aux(rj_handle h) {
   return hipStreamSynchronize(h->aux_stream);
 }
 
+// ---- "pip_concurrent" 2: which schedule for this pair? ------------------------------------------
+static void co_reset(rj_handle h) {
+  h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0;
+}
+static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
+  if (!h->co_measure) return;
+  h->co_measure = false;
+  if (hipEventQuery(h->ev[RJ_T_LSI_KERNEL][1]) != hipSuccess || hipEventQuery(h->ev[RJ_T_PIP_KERNEL][1]) != hipSuccess) return;
+  float a = 0, b = 0;
+  if (hipEventElapsedTime(&a, h->ev[RJ_T_LSI_KERNEL][0], h->ev[RJ_T_LSI_KERNEL][1]) != hipSuccess) return;
+  if (hipEventElapsedTime(&b, h->ev[RJ_T_LSI_KERNEL][0], h->ev[RJ_T_PIP_KERNEL][1]) != hipSuccess) return;
+  float span = a > b ? a : b, c = 0;
+  if (h->co_points && hipEventQuery(h->ev[RJ_T_LSI_POINTS][1]) == hipSuccess &&
+      hipEventElapsedTime(&c, h->ev[RJ_T_LSI_KERNEL][0], h->ev[RJ_T_LSI_POINTS][1]) == hipSuccess && c > span) span = c;
+  if (span < h->co_best[h->co_mode]) h->co_best[h->co_mode] = span;
+  if (++h->co_trials >= 6 && h->co_choice < 0) {
+    h->co_choice = 0;
+    for (int m = 1; m < 3; m++) if (h->co_best[m] < h->co_best[h->co_choice]) h->co_choice = m;
+  }
+}
+static int co_pick(rj_handle h, uint64_t n) {
+  co_collect(h);
+  if (h->co_n && (n > h->co_n + h->co_n / 4 || n + n / 4 < h->co_n)) co_reset(h);  // another query size: decide again
+  h->co_n = n;
+  return h->co_choice >= 0 ? h->co_choice : h->co_trials % 3;
+}
+
 uint64_t pad64(uint64_t n) { return (n + 63) / 64 * 64; }
 
 constexpr size_t kSchedBlockWords = 8 * 128 / 8 + 16;            // one scheduler block, in u64 words (+ the fault-pointer line)
@@ -214,6 +258,10 @@ int rj_create(int device_id, rj_handle* out) {
   rj_handle h = new (std::nothrow) rj_handle_s();
   if (!h) return RJ_E_NOMEM;
   h->device = device_id;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
+  }
   if (hipSetDevice(device_id) != hipSuccess) { delete h; return RJ_E_HIP; }
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RJ_E_HIP; }
   h->stream = h->own_stream;
@@ -265,11 +313,27 @@ int rj_sync(rj_handle h) {
   RJ_CHECK_H(h);
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipStreamSynchronize(h->stream));
+  h->lsi_shared = h->lsi_inflight = false;
   RJ_HIP(h, join_aux(h));
   return check_fault(h);
 }
 
 const char* rj_last_error_string(rj_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int rj_get_option(rj_handle h, const char* name, int64_t* value) {
+  RJ_CHECK_H(h);
+  if (!name || !value) return fail(h, RJ_E_INVALID, "rj_get_option: null argument");
+  if (!strcmp(name, "stats")) *value = h->stats_on;
+  else if (!strcmp(name, "chunk_groups")) *value = h->chunk_groups;
+  else if (!strcmp(name, "group_lanes")) *value = h->group_lanes;
+  else if (!strcmp(name, "max_blocks")) *value = h->max_blocks;
+  else if (!strcmp(name, "query_order")) *value = h->query_order;
+  else if (!strcmp(name, "pip_concurrent")) *value = h->pip_concurrent;
+  else if (!strcmp(name, "pip_schedule")) *value = h->pip_concurrent == 2 ? h->co_choice : (h->pip_concurrent == 1 ? 1 : 0);
+  else if (!strcmp(name, "pip_schedule_trials")) *value = h->co_trials;
+  else return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
+  return RJ_OK;
+}
 
 int rj_set_option(rj_handle h, const char* name, int64_t value) {
   RJ_CHECK_H(h);
@@ -278,8 +342,9 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "own_stream")) { h->stream = h->own_stream; return RJ_OK; }
   if (!strcmp(name, "pip_concurrent")) {
     if (join_aux(h) != hipSuccess) return fail(h, RJ_E_HIP, "pip_concurrent: stream sync failed");
-    if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "pip_concurrent: 0 never, 1 always, 2 auto");
+    if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "pip_concurrent: 0 never, 1 LSI and PIP queries come in pairs and share the chip, 2 the same if it measures faster");
     h->pip_concurrent = (int) value;
+    co_reset(h);
     return RJ_OK;
   }
   if (!strcmp(name, "query_order")) {
@@ -316,6 +381,7 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   RJ_CHECK_H(h);
   if (map_id < 0 || map_id > 1) return fail(h, RJ_E_INVALID, "map_id must be 0 or 1");
   RJ_HIP(h, join_aux(h));
+  co_reset(h);
   if ((np && !xy) || (nc && (!row_index || !left || !right))) return fail(h, RJ_E_INVALID, "null input array");
   if (np >= (1ull << 32) || nc > np) return fail(h, RJ_E_INVALID, "index_t is 32-bit: np < 2^32, nc <= np");
   if (nc && (row_index[0] != 0 || row_index[nc] != np)) return fail(h, RJ_E_INVALID, "row_index must start at 0 and end at np");
@@ -513,6 +579,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   } while (0);
   RJ_HIP(h, e);
   b.built = true;
+  co_reset(h);
   return RJ_OK;
 }
 
@@ -570,7 +637,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
 }
 
 static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
-                      uint64_t capacity, uint32_t* pairs_dev) {
+                      uint64_t capacity, uint32_t* pairs_dev, bool async_call = false) {
   if (base_map_id < 0 || base_map_id > 1 || query_map_id != 1 - base_map_id)
     return fail(h, RJ_E_INVALID, "rj_lsi_query: base/query map ids must be {0,1} and differ");
   if (!h->map[query_map_id].present) return fail(h, RJ_E_INVALID, "rj_lsi_query: query map not uploaded");
@@ -597,8 +664,23 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
-  tic(h, RJ_T_LSI_KERNEL);
-  if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, h->max_blocks));
+  // "pip_concurrent": the caller pairs every asynchronous LSI query with a PIP query (the step of a
+  // join).  k_lsi is latency-bound and k_pip VALU-bound, so the two SHARE the chip instead of taking
+  // turns: k_lsi runs on 1.25 blocks per CU, k_pip (second stream) on 5 -- per SIMD 5 x 80 + 1 x 72
+  // VGPRs and per CU 5 x 26 + 1..2 x 17 KiB of LDS fit together.  Measured, whole step of USCounty x
+  // BlockGroup: 1.39 ms instead of 1.52 taking turns (1.60 with both on full grids); 1/2, 1/4, 1/8
+  // shards 0.76 / 0.43 / 0.28 instead of 0.89 / 0.51 / 0.30.  Not for re-ordered or instrumented
+  // queries (shared scratch), and not for the synchronous rj_lsi_query (nothing can run beside it).
+  // "pip_concurrent" 2 decides per workload (co_pick above).
+  int max_blocks = h->max_blocks;
+  const bool pairable = async_call && h->pip_concurrent != 0 && !order && !h->stats_on && qe > qb;
+  h->co_mode = pairable ? (h->pip_concurrent == 2 ? co_pick(h, qe - qb) : 1) : 0;
+  h->lsi_inflight = async_call && qe > qb;
+  h->co_measure = h->co_points = false;
+  h->lsi_shared = pairable && h->co_mode == 1;
+  if (h->lsi_shared && h->cus * 5 / 4 < max_blocks) max_blocks = h->cus * 5 / 4;
+  tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
+  if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks));
   toc(h, RJ_T_LSI_KERNEL);
   return RJ_OK;
 }
@@ -606,7 +688,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
 int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, uint64_t qe,
                        uint64_t capacity, uint32_t* pairs_dev) {
   RJ_CHECK_H(h);
-  return lsi_launch(h, base_map_id, query_map_id, qb, qe, capacity, pairs_dev);
+  return lsi_launch(h, base_map_id, query_map_id, qb, qe, capacity, pairs_dev, true);
 }
 
 int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
@@ -615,6 +697,7 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter, 8, hipMemcpyDeviceToHost, h->stream));
   if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
+  h->lsi_shared = h->lsi_inflight = false;
   uint64_t n = h->h_pinned[0];
   if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
   if (n_found) *n_found = n;
@@ -657,6 +740,7 @@ int rj_lsi_points_async(rj_handle h, const uint32_t* pairs_dev, uint64_t capacit
   if (!h->map[0].present || !h->map[1].present) return fail(h, RJ_E_INVALID, "rj_lsi_points_async: both maps must be uploaded");
   if (capacity && (!pairs_dev || !out_dev)) return fail(h, RJ_E_INVALID, "rj_lsi_points_async: null buffer");
   if (int r = set_device(h)) return r;
+  if (h->lsi_inflight) h->co_points = true;
   tic(h, RJ_T_LSI_POINTS);
   RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, capacity, h->d_counter, (XsectRec*) out_dev));
   toc(h, RJ_T_LSI_POINTS);
@@ -706,16 +790,14 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   const uint32_t* order = nullptr;
   if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
-  // "pip_concurrent": the kernel goes to the handle's second stream and overlaps whatever runs on
-  // the main one (the LSI kernel of the same step: both only read the maps and the tree).  Not
+  // "pip_concurrent": the kernel goes to the handle's second stream and runs BESIDE the LSI kernel
+  // of the same step on the main stream (both only read the maps and the tree): with an LSI query in
+  // flight on its reduced grid (lsi_launch), on 5 blocks per CU; otherwise on the full grid.  Not
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
-  // Measured (USCounty x BlockGroup shards, tools/overlap_probe.py, whole step): beside the LSI kernel
-  // a 1/8 shard's step takes 0.34 instead of 0.44 ms, a 1/4 shard's 0.56 instead of 0.62, a 1/2
-  // shard's 0.94 instead of 0.96 -- each kernel alone leaves the chip partly idle in its ramp and
-  // tail -- while two full-size persistent kernels only get in each other's way (1.64 vs 1.58 ms);
-  // "auto" draws the line at 16 M points.
-  const bool small = n < (uint64_t) 16000000;
-  const bool aux = (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && small)) && !order && !h->stats_on;
+  const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight && h->co_mode != 0));
+  const int max_blocks = aux && h->lsi_shared && h->cus * 5 < h->max_blocks ? h->cus * 5 : h->max_blocks;
+  // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
+  h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !order && !h->stats_on && n > 0;
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
   // in flight together (calls on ONE stream are ordered by the stream)
@@ -734,7 +816,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_PIP_KERNEL, st);
-  if (n) RJ_HIP(h, launch_pip(st, a, h->stats_on, h->max_blocks));
+  if (n) RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
   toc(h, RJ_T_PIP_KERNEL, st);
   if (aux) h->aux_pending = true;
   return RJ_OK;

@@ -203,6 +203,52 @@ def test_pip_on_the_second_stream_beside_lsi(oracle, lattice_pair):
         h.set_option("pip_concurrent", 0)
 
 
+def test_auto_schedule_tries_all_and_settles(oracle, lattice_pair):
+    """ "pip_concurrent" 2: the first LSI + PIP pairs run in three ways (one after the other / sharing
+    the chip / beside each other on full grids), then the fastest schedule is kept; every step's results
+    are the same; a new query size or the option itself starts the decision again."""
+    ctx, dctx = lattice_pair
+    h = dctx.handle
+    m0 = _omap(oracle, ctx.maps[0])
+    want_pairs = oracle.lsi_brute(m0, _omap(oracle, ctx.maps[1]))
+    want_eids = oracle.pip_brute(m0, 1, ctx.maps[1].pts)
+    cap = 4 * len(want_pairs)
+    pairs = h.alloc(8 * cap)
+    xs = h.alloc(48 * cap)
+    closest = h.alloc(4 * ctx.maps[1].n_points)
+
+    def pair(ne):
+        h.lsi_query_async(0, 1, 0, ne, cap, pairs)
+        h.lsi_points_async(pairs, cap, xs)
+        h.pip_query(0, 1, None, 0, ctx.maps[1].n_points, closest, None, sync=False)
+        n = h.lsi_query_finish(cap)
+        h.sync()
+        return n
+    try:
+        h.set_option("query_order", 0)  # (re-ordered queries are never paired: shared scratch)
+        h.set_option("pip_concurrent", 2)
+        assert h.get_option("pip_concurrent") == 2 and h.get_option("pip_schedule") == -1
+        undecided = 0
+        for i in range(16):
+            n = pair(ctx.maps[1].n_edges)
+            assert n == len(want_pairs)
+            assert np.array_equal(closest.to_host(np.uint32), want_eids)
+            trials, choice = h.get_option("pip_schedule_trials"), h.get_option("pip_schedule")
+            assert trials <= i and (choice == -1) == (trials < 6), (i, trials, choice)  # (a pair is measured when the next one is launched)
+            undecided += choice == -1
+        assert 6 <= undecided < 16 and h.get_option("pip_schedule") in (0, 1, 2)
+        h.sort_pairs(pairs, n)
+        assert np.array_equal(pairs.to_host(np.uint32, 2 * n).reshape(-1, 2), want_pairs)
+        pair(ctx.maps[1].n_edges // 3)  # another query size: decide again
+        assert h.get_option("pip_schedule") == -1
+        h.set_option("pip_concurrent", 1)
+        assert h.get_option("pip_schedule") == 1
+    finally:
+        h.set_option("pip_concurrent", 0)
+        h.set_option("query_order", 1)
+    assert h.get_option("pip_schedule") == 0
+
+
 def test_two_handles_from_two_threads(oracle, lattice_pair):
     """A handle is not thread-safe, but different handles may be used from different threads
     (include/rayjoin_amd.h conventions); ctypes drops the GIL during the calls."""
