@@ -236,9 +236,13 @@ def main():
 
     # phase split (synchronous calls, wall clock), one extra untimed pass
     t0 = time.perf_counter(); h.lsi_query(0, 1, e0, e1, cap, pairs); t_lsi_wall = time.perf_counter() - t0
-    lsi_alone_ms = h.last_ms(_capi.RJ_T_LSI_KERNEL)  # (a synchronous query: the kernel has the chip to itself)
     t0 = time.perf_counter(); h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); t_pip_wall = time.perf_counter() - t0
-    pip_alone_ms = h.last_ms(_capi.RJ_T_PIP_KERNEL)
+    # each kernel with the chip to itself (synchronous queries), median of three
+    alone = {"lsi": [], "pip": []}
+    for _ in range(3):
+        h.lsi_query(0, 1, e0, e1, cap, pairs); alone["lsi"].append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
+        h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); alone["pip"].append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
+    lsi_alone_ms, pip_alone_ms = float(np.median(alone["lsi"])), float(np.median(alone["pip"]))
 
     checks = None
     if args.check and rank == 0 and world == 1:
@@ -258,7 +262,7 @@ def main():
         if os.path.exists(tp) and headline:
             doc = json.load(open(tp))
             if doc.get("kernel_source_hash") == _capi.kernel_source_hash():
-                traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_*" % doc.get("tag")
+                traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_* (counter passes: each kernel alone on its full grid)" % doc.get("tag")
             else:
                 prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
         roof = {}

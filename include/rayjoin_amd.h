@@ -231,9 +231,9 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * both only read the maps and the index) and the two kernels may run beside each other instead of
  * taking turns: with 1 the LSI kernel runs on 1.25 blocks per compute unit and the PIP kernel, on a
  * second stream owned by the handle, on 5.  That is faster on some workloads and slower on others,
- * so "auto" runs the first six pairs in three ways (taking turns / sharing the chip as above / beside
- * each other on full grids), keeps the fastest, and decides again when the index, a map or the query
- * size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
+ * so "auto" runs the first six pairs in three ways, twice each (taking turns / sharing the chip as
+ * above / beside each other on full grids), keeps the fastest, and decides again when the index, a
+ * map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
  * rj_lsi_query and a PIP query without an LSI query in flight always use the whole chip.)  The PIP
  * query's inputs must be complete when the call
  * is made; its outputs are complete after rj_sync, rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL). */

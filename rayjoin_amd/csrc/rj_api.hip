@@ -73,7 +73,8 @@ struct rj_handle_s {
   // other, each on its own full grid (whichever starts first fills the chip, the other fills its
   // ramp and tail).  Which one wins depends on the workload (headline pair: 1 by 9 %; 24-67 M-segment
   // trees: 0 by 35 % over 1; a 1/8 shard against the 24 M-segment tree: 2), so the first pairs run
-  // 0, 1, 2, 0, 1, 2 and the fastest is kept until the index, the maps or the query size change.
+  // 0, 1, 2, 0, 1, 2 (a schedule's first run pays one-time costs: best of two) and the fastest is kept
+  // until the index, the maps or the query size change.
   // The span of a pair = start of its LSI kernel .. end of the last of k_lsi, k_lsi_points, k_pip.
   int co_trials = 0;          // pairs measured so far
   float co_best[3] = {1e30f, 1e30f, 1e30f};  // best span [ms] per schedule
@@ -215,7 +216,7 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
   float span = a > b ? a : b, c = 0;
   if (h->co_points && hipEventQuery(h->ev[RJ_T_LSI_POINTS][1]) == hipSuccess &&
       hipEventElapsedTime(&c, h->ev[RJ_T_LSI_KERNEL][0], h->ev[RJ_T_LSI_POINTS][1]) == hipSuccess && c > span) span = c;
-  if (span < h->co_best[h->co_mode]) h->co_best[h->co_mode] = span;
+  if (span < h->co_best[h->co_mode]) h->co_best[h->co_mode] = span;  // (best of two: a schedule's first run pays one-time costs)
   if (++h->co_trials >= 6 && h->co_choice < 0) {
     h->co_choice = 0;
     for (int m = 1; m < 3; m++) if (h->co_best[m] < h->co_best[h->co_choice]) h->co_choice = m;

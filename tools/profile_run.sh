@@ -5,16 +5,19 @@
 #   python tools/pmc_summary.py <tag> gpurun_out/<tag>_fetch gpurun_out/<tag>_write
 #   cp gpurun_out/<tag>_kt/*kernel_stats.csv profiles/<tag>_kernel_stats.csv
 #   cp gpurun_out/<tag>_bench.json profiles/<tag>_bench.json
-# Counter passes are separate runs with --kernel-trace only (never combined with other traces).
+# Counter passes are separate runs with --kernel-trace only (never combined with other traces); rocprofv3
+# serialises the kernels of a counter pass, so they run with --serial-kernels: the counters describe each
+# kernel alone on its full grid, whatever schedule the timed steps of a normal run settle on.
 set -e -o pipefail
 TAG=${1:?tag}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o g -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_kt.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -o g -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -o g -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${TAG}_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq1 -o g -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq1.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq2 -o g -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq2.log 2>&1
+# (40 timed steps: the first six steps of a run try the three kernel schedules, the average should be about the chosen one)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o g -- python3 $R/bench.py --no-cpu-baseline --steps 40 > $R/gpurun_out/${TAG}_kt.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels > $R/gpurun_out/${TAG}_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels > $R/gpurun_out/${TAG}_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq1 -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq1.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq2 -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq2.log 2>&1
 cd $R
 timeout -k 10 500 python3 bench.py --check 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench.json
 tail -c 300 gpurun_out/${TAG}_bench.json
