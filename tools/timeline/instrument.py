@@ -46,10 +46,10 @@ def patch_kernel(k, name, light, group_tail_old, group_tail_new):
     if name == "k_lsi":
         body = sub(body, "  for (uint64_t g = g_begin; g < g_end; g++) {\n", "  for (uint64_t g = g_begin; g < g_end; g++) {\n@START@")
     else:
-        call = "    if (!next_group(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;\n"
+        call = "    if (!next_group<kPipWaves>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;\n"
         body = sub(body, call,
                    "    const unsigned long long tl_s0 = wall_clock64();\n"
-                   "    const bool tl_ok = next_group(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32);\n"
+                   "    const bool tl_ok = next_group<kPipWaves>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32);\n"
                    "    tl_sched += wall_clock64() - tl_s0;\n"
                    "    if (!tl_ok) break;\n"
                    "    if (!tl_first) tl_first = wall_clock64();\n")
@@ -126,7 +126,7 @@ def main():
         "    FILE* fp = fopen(path, \"wb\");\n"
         "    if (fp) { fwrite(tl_host, 1, sizeof tl_host, fp); fclose(fp); }\n"
         "  }\n" % WORDS)
-    a = sub(a, "  tic(h, RJ_T_LSI_KERNEL);\n", hook.replace("@ST@", "h->stream").replace("@SLOT@", "0") + "  tic(h, RJ_T_LSI_KERNEL);\n")
+    a = sub(a, "  tic(h, RJ_T_LSI_KERNEL);  // (after co_pick", hook.replace("@ST@", "h->stream").replace("@SLOT@", "0") + "  tic(h, RJ_T_LSI_KERNEL);  // (after co_pick")
     a = sub(a, "  toc(h, RJ_T_LSI_KERNEL);\n", "  toc(h, RJ_T_LSI_KERNEL);\n" + dump.replace("@ST@", "h->stream").replace("@KIND@", "lsi"))
     a = sub(a, "  tic(h, RJ_T_PIP_KERNEL, st);\n", hook.replace("@ST@", "st").replace("@SLOT@", "1") + "  tic(h, RJ_T_PIP_KERNEL, st);\n")
     a = sub(a, "  toc(h, RJ_T_PIP_KERNEL, st);\n", "  toc(h, RJ_T_PIP_KERNEL, st);\n" + dump.replace("@ST@", "st").replace("@KIND@", "pip"))
