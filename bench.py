@@ -209,7 +209,8 @@ def main():
     else:
         n_x = state["n"]
     ms_per_step = elapsed * 1e3 / args.steps
-    schedule = h.get_option("pip_schedule")
+    schedule = h.get_option("pip_schedule")  # (read now: a later index build starts the decision again)
+    share = (h.get_option("lsi_share_blocks"), h.get_option("pip_share_blocks"))
 
     # order-independent digest of the step's results, summed over ranks (untimed): lets a test compare
     # an N-rank run with the single-GPU run of the same workload without shipping the results
@@ -305,7 +306,7 @@ def main():
                                                       "DIAGNOSTIC: rank 0's shard of a %d-way run on one GPU, value is NOT a job throughput" % args.emulate_shard),
                        "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale,
                        # what rj_set_option("pip_concurrent", 2) settled on for this workload (rank 0)
-                       "kernel_schedule": {1: "k_lsi and k_pip share the chip (1.25 + 5 blocks per CU)", 0: "k_lsi, then k_pip",
+                       "kernel_schedule": {1: "k_lsi and k_pip share the chip (%d + %d blocks)" % share, 0: "k_lsi, then k_pip",
                                            2: "k_lsi and k_pip beside each other, each on its full grid",
                                            -1: "undecided (fewer than 7 paired steps)"}[schedule]},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),

@@ -230,7 +230,8 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * 2 auto: the caller issues rj_lsi_query_async and rj_pip_query_async in PAIRS (the step of a join:
  * both only read the maps and the index) and the two kernels may run beside each other instead of
  * taking turns: with 1 the LSI kernel runs on 1.25 blocks per compute unit and the PIP kernel, on a
- * second stream owned by the handle, on 5.  That is faster on some workloads and slower on others,
+ * second stream owned by the handle, on 5 (with 2 the split follows the measured work of the two sides:
+ * up to 2.25 + 4).  That is faster on some workloads and slower on others,
  * so "auto" runs the first six pairs in three ways, twice each (taking turns / sharing the chip as
  * above / beside each other on full grids), keeps the fastest, and decides again when the index, a
  * map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
@@ -240,7 +241,8 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 /* current value of an option of rj_set_option; additionally "pip_schedule": what "pip_concurrent" 2 has
  * decided for the current workload (0 taking turns, 1 sharing the chip, 2 beside each other on full grids,
- * -1 still trying) and "pip_schedule_trials": the pairs it has measured so far. */
+ * -1 still trying), "pip_schedule_trials": the pairs it has measured so far, "lsi_share_blocks" /
+ * "pip_share_blocks": the grids of schedule 1. */
 int rj_get_option(rj_handle h, const char* name, int64_t* value);
 
 /* ---- device memory helpers (for hosts without their own allocator) -------------------- */

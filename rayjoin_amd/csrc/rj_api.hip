@@ -69,11 +69,11 @@ struct rj_handle_s {
   bool lsi_inflight = false;  // an asynchronous LSI query was launched and not yet finished / synced
   bool lsi_shared = false;    // ... on a reduced grid, waiting for its PIP partner
   // "pip_concurrent" 2: three schedules for an LSI + PIP pair -- 0: one after the other on the main
-  // stream; 1: beside each other on shared grids (k_lsi 1.25 blocks per CU, k_pip 5); 2: beside each
+  // stream; 1: beside each other on shared grids (k_lsi 1.25-2.25 blocks per CU, k_pip 5-4, see co_ratio); 2: beside each
   // other, each on its own full grid (whichever starts first fills the chip, the other fills its
   // ramp and tail).  Which one wins depends on the workload (headline pair: 1 by 9 %; 24-67 M-segment
   // trees: 0 by 35 % over 1; a 1/8 shard against the 24 M-segment tree: 2), so the first pairs run
-  // 0, 1, 2, 0, 1, 2 (a schedule's first run pays one-time costs: best of two) and the fastest is kept
+  // 0, 0, 1, 2, 1, 2 (a schedule's first run pays one-time costs: best of two) and the fastest is kept
   // until the index, the maps or the query size change.
   // The span of a pair = start of its LSI kernel .. end of the last of k_lsi, k_lsi_points, k_pip.
   int co_trials = 0;          // pairs measured so far
@@ -83,6 +83,12 @@ struct rj_handle_s {
   bool co_measure = false;    // the pair in flight is complete (LSI + PIP): its span can be read
   bool co_points = false;     // ... and k_lsi_points ran between them
   uint64_t co_n = 0;          // query size the decision was made for
+  // how the chip is split when shared: both sides should end together, so k_lsi's share follows the
+  // ratio of the two sides' solo times seen in the "taking turns" trial, (k_lsi + k_lsi_points) / k_pip --
+  // measured optima: ratio 0.41 (headline pair) -> 320 + 1280 blocks, 0.72 (nested pair, WaterBodies) -> 576 + 1024
+  float co_ratio = 0.41f;
+  int lsi_share_blocks() const { int b = ((int) (780.0f * co_ratio * (float) cus / 256.0f) + 32) / 64 * 64; return b < cus * 3 / 4 ? cus * 3 / 4 : (b > cus * 4 ? cus * 4 : b); }
+  int pip_share_blocks() const { return lsi_share_blocks() <= cus * 7 / 4 ? cus * 5 : cus * 4; }
   bool aux_pending = false;          // something was enqueued on aux_stream since it was last joined
   hipStream_t stream = nullptr;
   MapState map[2];
@@ -205,6 +211,7 @@ hipError_t join_aux(rj_handle h) {
 // ---- "pip_concurrent" 2: which schedule for this pair? ------------------------------------------
 static void co_reset(rj_handle h) {
   h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0;
+  h->co_ratio = 0.41f;
 }
 static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
   if (!h->co_measure) return;
@@ -216,6 +223,13 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
   float span = a > b ? a : b, c = 0;
   if (h->co_points && hipEventQuery(h->ev[RJ_T_LSI_POINTS][1]) == hipSuccess &&
       hipEventElapsedTime(&c, h->ev[RJ_T_LSI_KERNEL][0], h->ev[RJ_T_LSI_POINTS][1]) == hipSuccess && c > span) span = c;
+  if (h->co_mode == 0) {  // taking turns: the solo times of the two sides set the split of the shared schedule
+    float pip = 0, pts = 0;
+    if (hipEventElapsedTime(&pip, h->ev[RJ_T_PIP_KERNEL][0], h->ev[RJ_T_PIP_KERNEL][1]) == hipSuccess && pip > 0) {
+      if (h->co_points && c > 0) (void) hipEventElapsedTime(&pts, h->ev[RJ_T_LSI_POINTS][0], h->ev[RJ_T_LSI_POINTS][1]);
+      h->co_ratio = (a + pts) / pip;
+    }
+  }
   if (span < h->co_best[h->co_mode]) h->co_best[h->co_mode] = span;  // (best of two: a schedule's first run pays one-time costs)
   if (++h->co_trials >= 6 && h->co_choice < 0) {
     h->co_choice = 0;
@@ -226,7 +240,8 @@ static int co_pick(rj_handle h, uint64_t n) {
   co_collect(h);
   if (h->co_n && (n > h->co_n + h->co_n / 4 || n + n / 4 < h->co_n)) co_reset(h);  // another query size: decide again
   h->co_n = n;
-  return h->co_choice >= 0 ? h->co_choice : h->co_trials % 3;
+  static const int kTrial[6] = {0, 0, 1, 2, 1, 2};  // (turns first: it also measures the split for 1)
+  return h->co_choice >= 0 ? h->co_choice : kTrial[h->co_trials < 6 ? h->co_trials : 5];
 }
 
 uint64_t pad64(uint64_t n) { return (n + 63) / 64 * 64; }
@@ -332,6 +347,8 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_concurrent")) *value = h->pip_concurrent;
   else if (!strcmp(name, "pip_schedule")) *value = h->pip_concurrent == 2 ? h->co_choice : (h->pip_concurrent == 1 ? 1 : 0);
   else if (!strcmp(name, "pip_schedule_trials")) *value = h->co_trials;
+  else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
+  else if (!strcmp(name, "pip_share_blocks")) *value = h->pip_share_blocks();
   else return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
   return RJ_OK;
 }
@@ -667,7 +684,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.stats = h->stats_on ? h->d_stats : nullptr;
   // "pip_concurrent": the caller pairs every asynchronous LSI query with a PIP query (the step of a
   // join).  k_lsi is latency-bound and k_pip VALU-bound, so the two SHARE the chip instead of taking
-  // turns: k_lsi runs on 1.25 blocks per CU, k_pip (second stream) on 5 -- per SIMD 5 x 80 + 1 x 72
+  // turns: k_lsi runs on 1.25 blocks per CU (more when its side of the step is the heavier one: co_ratio), k_pip (second stream) on 5 -- per SIMD 5 x 80 + 1 x 72
   // VGPRs and per CU 5 x 26 + 1..2 x 17 KiB of LDS fit together.  Measured, whole step of USCounty x
   // BlockGroup: 1.39 ms instead of 1.52 taking turns (1.60 with both on full grids); 1/2, 1/4, 1/8
   // shards 0.76 / 0.43 / 0.28 instead of 0.89 / 0.51 / 0.30.  Not for re-ordered or instrumented
@@ -679,7 +696,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   h->lsi_inflight = async_call && qe > qb;
   h->co_measure = h->co_points = false;
   h->lsi_shared = pairable && h->co_mode == 1;
-  if (h->lsi_shared && h->cus * 5 / 4 < max_blocks) max_blocks = h->cus * 5 / 4;
+  if (h->lsi_shared && h->lsi_share_blocks() < max_blocks) max_blocks = h->lsi_share_blocks();
   tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
   if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks));
   toc(h, RJ_T_LSI_KERNEL);
@@ -796,7 +813,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // flight on its reduced grid (lsi_launch), on 5 blocks per CU; otherwise on the full grid.  Not
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
   const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight && h->co_mode != 0));
-  const int max_blocks = aux && h->lsi_shared && h->cus * 5 < h->max_blocks ? h->cus * 5 : h->max_blocks;
+  const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
   h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !order && !h->stats_on && n > 0;
   hipStream_t st = aux ? h->aux_stream : h->stream;
