@@ -663,8 +663,10 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (qb > qe || qe > h->map[query_map_id].ne) return fail(h, RJ_E_INVALID, "rj_lsi_query: bad query eid range");
   if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query: null output");
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear (queue.h:125-129)
-  RJ_HIP(h, hipMemsetAsync(h->d_counter + kSchedLsi, 0, kSchedZeroBytes, h->stream));
+  // Queue::Clear (queue.h:125-129) and the scheduler counters in ONE fill: the result count [0] and the
+  // scheduler block are 128 bytes apart, and the words between them are scratch that their users clear
+  // themselves (a second fill kernel costs the step 6-8 us of launch gap in front of k_lsi)
+  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, kSchedLsi * 8 + kSchedZeroBytes, h->stream));
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   const uint32_t* order = nullptr;
   if (int r = maybe_order_queries(h, false, nullptr, h->map[query_map_id].seg, qb, qe - qb, &order, query_map_id, qb)) return r;
