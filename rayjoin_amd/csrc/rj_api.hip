@@ -93,9 +93,11 @@ struct rj_handle_s {
   hipStream_t stream = nullptr;
   MapState map[2];
   BvhState bvh[2];
-  // d_counter (u64 words): [0] LSI result count; [2],[3] grid build; [4],[5] group-extent estimate;
+  // d_counter (u64 words): [0],[1] LSI result count (alternating: flip_lsi), [6] the grid LSI's; [2],[3] grid build; [4],[5] group-extent estimate;
   // then three scheduler blocks of 8 counters 128 B apart: LSI, PIP on the main stream, PIP on aux
   unsigned long long* d_counter = nullptr;
+  int flip_lsi = 0, flip_pip[2] = {0, 0};  // which of the two counter sets the next launch uses (LSI; PIP on main / aux stream)
+  size_t count_word = 0;                   // where the latest LSI query's result count lives
   unsigned long long* d_stats = nullptr;    // [16]
   unsigned long long* h_pinned = nullptr;   // [32] pinned read-back area
   // Traversal-stack fault words, [0] LSI [1] PIP: pinned host memory the kernels write directly
@@ -247,9 +249,12 @@ static int co_pick(rj_handle h, uint64_t n) {
 uint64_t pad64(uint64_t n) { return (n + 63) / 64 * 64; }
 
 constexpr size_t kSchedBlockWords = 8 * 128 / 8 + 16;            // one scheduler block, in u64 words (+ the fault-pointer line)
-constexpr size_t kSchedZeroBytes = 8 * 128;                      // what is cleared before a launch
-constexpr size_t kSchedLsi = 16, kSchedPipMain = kSchedLsi + kSchedBlockWords, kSchedPipAux = kSchedPipMain + kSchedBlockWords;
-constexpr size_t kCounterBytes = (kSchedPipAux + kSchedBlockWords) * 8;
+// Every kernel kind has TWO scheduler blocks per stream (and k_lsi two result counts, words [0] and [1]): a
+// launch uses one and clears the other for the next launch on that stream, so no fill kernel sits between
+// the host's call and the kernel (each cost the step 6-8 us of launch gap).
+constexpr size_t kSchedLsi = 16, kSchedPipMain = kSchedLsi + 2 * kSchedBlockWords, kSchedPipAux = kSchedPipMain + 2 * kSchedBlockWords;
+constexpr size_t kCounterBytes = (kSchedPipAux + 2 * kSchedBlockWords) * 8;
+constexpr size_t kGridLsiCountWord = 6;  // rj_lsi_query_grid's result count (cleared by a fill: not on the hot path)
 
 // after a stream sync: did a traversal stack overflow?  (cannot for an index rj_build_lbvh accepted)
 int check_fault(rj_handle h) {
@@ -290,7 +295,8 @@ int rj_create(int device_id, rj_handle* out) {
   if (ok) {
     h->h_fault[0] = h->h_fault[1] = 0;
     ok = hipMemset(h->d_counter, 0, kCounterBytes) == hipSuccess;
-    for (size_t blk : {kSchedLsi, kSchedPipMain, kSchedPipAux})  // behind each block's counters: where its kernel reports a fault
+    for (size_t blk : {kSchedLsi, kSchedLsi + kSchedBlockWords, kSchedPipMain, kSchedPipMain + kSchedBlockWords, kSchedPipAux,
+                       kSchedPipAux + kSchedBlockWords})  // behind each block's counters: where its kernel reports a fault
       ok = ok && hipMemcpy((char*) (h->d_counter + blk) + kSchedFaultPtrWord * 4, &h->d_fault, sizeof(h->d_fault), hipMemcpyHostToDevice) == hipSuccess;
   }
   for (int t = 0; ok && t < kNumTimers; t++)
@@ -663,10 +669,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (qb > qe || qe > h->map[query_map_id].ne) return fail(h, RJ_E_INVALID, "rj_lsi_query: bad query eid range");
   if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query: null output");
   if (int r = set_device(h)) return r;
-  // Queue::Clear (queue.h:125-129) and the scheduler counters in ONE fill: the result count [0] and the
-  // scheduler block are 128 bytes apart, and the words between them are scratch that their users clear
-  // themselves (a second fill kernel costs the step 6-8 us of launch gap in front of k_lsi)
-  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, kSchedLsi * 8 + kSchedZeroBytes, h->stream));
+  // Queue::Clear (queue.h:125-129) and the scheduler counters: cleared by the previous launch (see kSchedLsi)
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   const uint32_t* order = nullptr;
   if (int r = maybe_order_queries(h, false, nullptr, h->map[query_map_id].seg, qb, qe - qb, &order, query_map_id, qb)) return r;
@@ -678,8 +681,11 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.qbeg = qb; a.qend = qe;
   a.base_is_map0 = base_map_id == 0;
   a.out = pairs_dev; a.cap = capacity;
-  a.counter = h->d_counter;
-  a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi);
+  const int flip = h->flip_lsi;
+  a.counter = h->d_counter + flip;
+  a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi + flip * kSchedBlockWords);
+  a.next_counter = h->d_counter + (1 - flip);
+  a.next_work_counter = (unsigned int*) (h->d_counter + kSchedLsi + (1 - flip) * kSchedBlockWords);
   a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 8);
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
@@ -700,7 +706,13 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   h->lsi_shared = pairable && h->co_mode == 1;
   if (h->lsi_shared && h->lsi_share_blocks() < max_blocks) max_blocks = h->lsi_share_blocks();
   tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
-  if (qe > qb) RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks));
+  if (qe > qb) {
+    RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks));
+    h->flip_lsi = 1 - flip;
+  } else {
+    RJ_HIP(h, hipMemsetAsync(a.counter, 0, 8, h->stream));  // (an empty query: nothing ran that could have counted)
+  }
+  h->count_word = (size_t) flip;
   toc(h, RJ_T_LSI_KERNEL);
   return RJ_OK;
 }
@@ -714,7 +726,7 @@ int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t 
 int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   RJ_CHECK_H(h);
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter, 8, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream));
   if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   h->lsi_shared = h->lsi_inflight = false;
@@ -732,7 +744,7 @@ int rj_lsi_count_to(rj_handle h, uint64_t* n_found_dev) {
   RJ_CHECK_H(h);
   if (!n_found_dev) return fail(h, RJ_E_INVALID, "rj_lsi_count_to: null destination");
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipMemcpyAsync(n_found_dev, h->d_counter, 8, hipMemcpyDeviceToDevice, h->stream));
+  RJ_HIP(h, hipMemcpyAsync(n_found_dev, h->d_counter + h->count_word, 8, hipMemcpyDeviceToDevice, h->stream));
   return RJ_OK;
 }
 
@@ -762,7 +774,7 @@ int rj_lsi_points_async(rj_handle h, const uint32_t* pairs_dev, uint64_t capacit
   if (int r = set_device(h)) return r;
   if (h->lsi_inflight) h->co_points = true;
   tic(h, RJ_T_LSI_POINTS);
-  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, capacity, h->d_counter, (XsectRec*) out_dev));
+  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, capacity, h->d_counter + h->count_word, (XsectRec*) out_dev));
   toc(h, RJ_T_LSI_POINTS);
   return RJ_OK;
 }
@@ -821,8 +833,8 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
   // in flight together (calls on ONE stream are ordered by the stream)
-  unsigned long long* sched = h->d_counter + (aux ? kSchedPipAux : kSchedPipMain);
-  RJ_HIP(h, hipMemsetAsync(sched, 0, kSchedZeroBytes, st));
+  const int pflip = h->flip_pip[aux ? 1 : 0];  // (cleared by the previous launch on this stream, see kSchedLsi)
+  unsigned long long* sched = h->d_counter + (aux ? kSchedPipAux : kSchedPipMain) + pflip * kSchedBlockWords;
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
   a.base = map_view(h->map[base_map_id]);
@@ -831,12 +843,16 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.query_map_id = query_map_id;
   a.closest = closest_eid_dev; a.face = face_id_dev;
   a.work_counter = (unsigned int*) sched;
+  a.next_work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedPipAux : kSchedPipMain) + (1 - pflip) * kSchedBlockWords);
   a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 6);
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   tic(h, RJ_T_PIP_KERNEL, st);
-  if (n) RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
+  if (n) {
+    RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
+    h->flip_pip[aux ? 1 : 0] = 1 - pflip;
+  }
   toc(h, RJ_T_PIP_KERNEL, st);
   if (aux) h->aux_pending = true;
   return RJ_OK;
@@ -923,12 +939,13 @@ int rj_lsi_query_grid(rj_handle h, uint64_t capacity, uint32_t* pairs_dev, uint6
     return fail(h, RJ_E_INVALID, "rj_lsi_query_grid: call rj_build_grid for both maps with the same grid_size first");
   if (capacity && !pairs_dev) return fail(h, RJ_E_INVALID, "rj_lsi_query_grid: null output");
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipMemsetAsync(h->d_counter, 0, 8, h->stream));  // Queue::Clear
+  RJ_HIP(h, hipMemsetAsync(h->d_counter + kGridLsiCountWord, 0, 8, h->stream));  // Queue::Clear
+  h->count_word = kGridLsiCountWord;
   GridLsiArgs a;
   a.g = g0.g; a.scale = g0.scale;
   a.begin0 = g0.begin; a.eids0 = g0.eids; a.begin1 = g1.begin; a.eids1 = g1.eids;
   a.seg0 = h->map[0].seg; a.seg1 = h->map[1].seg;
-  a.out = pairs_dev; a.cap = capacity; a.counter = h->d_counter;
+  a.out = pairs_dev; a.cap = capacity; a.counter = h->d_counter + kGridLsiCountWord;
   tic(h, RJ_T_LSI_KERNEL);
   RJ_HIP(h, launch_lsi_grid(h->stream, a));
   toc(h, RJ_T_LSI_KERNEL);

@@ -22,7 +22,10 @@ struct LsiArgs {
   uint32_t* out;       // pairs out [2*cap]
   uint64_t cap;
   unsigned long long* counter;  // result count
-  unsigned int* work_counter;   // dynamic chunk scheduler (zeroed before every launch)
+  unsigned int* work_counter;   // dynamic chunk scheduler (zero when the kernel starts)
+  // the counters of the NEXT launch on this stream: this kernel clears them (no fill kernels between launches)
+  unsigned long long* next_counter;
+  unsigned int* next_work_counter;
   uint32_t chunk_groups;        // consecutive groups per chunk
   uint32_t group_lanes;         // queries per wave (0 = choose from the query count)
   int stack_cap;                // instrumented kernel only: use fewer stack entries (tests of the fault path)
@@ -39,6 +42,7 @@ struct PipArgs {
   uint32_t* closest;   // [n]
   int32_t* face;       // [n] or nullptr
   unsigned int* work_counter;
+  unsigned int* next_work_counter;  // the next launch's scheduler counters on this stream: cleared by this kernel
   uint32_t chunk_groups;
   uint32_t group_lanes;  // points per wave (0 = choose from the point count)
   int stack_cap;         // instrumented kernel only: use fewer stack entries (tests of the fault path)

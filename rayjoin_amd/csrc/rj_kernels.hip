@@ -511,6 +511,9 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
   const uint32_t GL = A.group_lanes;  // queries per wave: 64, or fewer for small query sets (more waves, shorter chains)
   const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
+  // (this launch's counters were cleared by the previous launch on the stream; it clears the next one's)
+  if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 8) *A.next_counter = 0;
   const bool occ_usable = T.occ[(size_t) kOccDim * kOccRowWords] == 0;  // every base segment was rasterised
   const int stack_cap = STATS && A.stack_cap < kStackEntries ? A.stack_cap : kStackEntries;  // (lowered only by tests of the fault path, instrumented kernel)
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
@@ -823,6 +826,7 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
   int part = blockIdx.x & 7, tried = 0;
   __shared__ unsigned long long ranges[kPipWaves];  // per wave {end : next}: the unstarted rest of its chunk
   if (threadIdx.x < kPipWaves) ranges[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 72) A.next_work_counter[(threadIdx.x - 64) * 32] = 0;  // (see k_lsi)
   __syncthreads();
   for (;;) {  // XCD-aware dynamic chunked scheduling, see next_chunk / next_group
   {
