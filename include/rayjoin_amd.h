@@ -67,7 +67,8 @@ int rj_create(int device_id, rj_handle* out);
 int rj_destroy(rj_handle h);
 /* run all work of this handle on a caller-owned hipStream_t; NULL is HIP's null (legacy default)
  * stream.  A new handle uses a private non-blocking stream (rj_set_option(h,"own_stream",1)
- * returns to it). */
+ * returns to it).  Change streams only while the handle is idle (after rj_sync): queries on one
+ * stream are ordered by the stream, and each query kernel prepares the counters of the next. */
 int rj_set_stream(rj_handle h, void* hip_stream);
 int rj_sync(rj_handle h);
 const char* rj_last_error_string(rj_handle h);
