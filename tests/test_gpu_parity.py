@@ -249,6 +249,52 @@ def test_auto_schedule_tries_all_and_settles(oracle, lattice_pair):
     assert h.get_option("pip_schedule") == 0
 
 
+def test_counter_sets_alternate_without_fill_kernels(oracle, lattice_pair):
+    """No fill kernel clears the result count or the scheduler counters: every query kernel clears the set
+    the NEXT launch on its stream uses (two sets, alternating).  Sequences that would expose a stale
+    set: an odd number of launches, back-to-back asynchronous queries of different ranges without a
+    finish in between, empty queries, the grid LSI (its own count word) in between, PIP on both streams."""
+    ctx, dctx = lattice_pair
+    h = dctx.handle
+    q = ctx.maps[1]
+    m0, m1 = _omap(oracle, ctx.maps[0]), _omap(oracle, q)
+    want = oracle.lsi_brute(m0, m1)
+    want_eids = oracle.pip_brute(m0, 1, q.pts)
+    half = q.n_edges // 2
+    n_half = int((want[:, 1] < half).sum())
+    cap = 4 * len(want)
+    pairs, pairs2 = h.alloc(8 * cap), h.alloc(8 * cap)
+    xs = h.alloc(48 * cap)
+    closest = h.alloc(4 * q.n_points)
+    h.build_grid(0, 64); h.build_grid(1, 64)
+    try:
+        for rep in range(5):  # (odd: the sets end up swapped for the next test)
+            # two launches in flight, the second one's count is the one that is read
+            h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs2)
+            h.lsi_query_async(0, 1, 0, half, cap, pairs)
+            h.lsi_points_async(pairs, cap, xs)
+            assert h.lsi_query_finish(cap) == n_half
+            # an empty query reports 0 and does not disturb the sets
+            h.lsi_query_async(0, 1, 7, 7, cap, pairs)
+            assert h.lsi_query_finish(cap) == 0
+            assert h.lsi_query(0, 1, 0, q.n_edges, cap, pairs) == len(want)
+            # the grid LSI has its own count word
+            assert h.lsi_query_grid(cap, pairs2) == len(want)
+            assert h.lsi_query(0, 1, 0, half, cap, pairs) == n_half
+            # PIP: main stream, second stream, empty, in a row
+            for mode in (0, 1, 1, 0):
+                h.set_option("pip_concurrent", mode)
+                h.pip_query(0, 1, None, 0, 0, closest, None, sync=False)
+                h.pip_query(0, 1, None, 0, q.n_points, closest, None, sync=False)
+                h.sync()
+                assert np.array_equal(closest.to_host(np.uint32), want_eids), (rep, mode)
+        h.lsi_query(0, 1, 0, q.n_edges, cap, pairs)
+        h.sort_pairs(pairs, len(want))
+        assert np.array_equal(pairs.to_host(np.uint32, 2 * len(want)).reshape(-1, 2), want)
+    finally:
+        h.set_option("pip_concurrent", 0)
+
+
 def test_two_handles_from_two_threads(oracle, lattice_pair):
     """A handle is not thread-safe, but different handles may be used from different threads
     (include/rayjoin_amd.h conventions); ctypes drops the GIL during the calls."""
