@@ -168,10 +168,16 @@ def main():
     def step(record):
         # everything is enqueued back to back; the step's single host sync is the count read-back
         h.lsi_query_async(0, 1, e0, e1, cap, pairs)
+        # once the handle has settled on running the two kernels beside each other, the PIP query -- the longer
+        # side, on the handle's second stream -- is issued right behind the LSI query (8-10 us earlier)
+        early = h.get_option("pip_schedule") in (1, 2)
+        if early:
+            h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
         h.lsi_points_async(pairs, cap, xsects)  # the records of this rank's hits (count read on the device)
         if world > 1:
             ex.begin(h)
-        h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+        if not early:
+            h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
         if world > 1:  # RCCL all-gather-v of the intersection queues (rank order, zero-copy views)
             state["pairs_all"], state["cnt_all"] = ex.finish()
             n = state["cnt_all"][rank]
