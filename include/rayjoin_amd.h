@@ -67,8 +67,9 @@ int rj_create(int device_id, rj_handle* out);
 int rj_destroy(rj_handle h);
 /* run all work of this handle on a caller-owned hipStream_t; NULL is HIP's null (legacy default)
  * stream.  A new handle uses a private non-blocking stream (rj_set_option(h,"own_stream",1)
- * returns to it).  Change streams only while the handle is idle (after rj_sync): queries on one
- * stream are ordered by the stream, and each query kernel prepares the counters of the next. */
+ * returns to it).  Queries on one stream are ordered by the stream, and each query kernel prepares
+ * the counters of the next, so a CHANGE of stream first drains the old one (and the handle's second
+ * stream); setting the stream the handle already uses costs nothing. */
 int rj_set_stream(rj_handle h, void* hip_stream);
 int rj_sync(rj_handle h);
 const char* rj_last_error_string(rj_handle h);
@@ -233,9 +234,9 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * taking turns: with 1 the LSI kernel runs on 1.25 blocks per compute unit and the PIP kernel, on a
  * second stream owned by the handle, on 5 (with 2 the split follows the measured work of the two sides:
  * up to 2.25 + 4).  That is faster on some workloads and slower on others,
- * so "auto" runs the first six pairs in three ways, twice each (taking turns / sharing the chip as
- * above / beside each other on full grids), keeps the fastest, and decides again when the index, a
- * map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
+ * so "auto" measures the first four pairs (taking turns / sharing the chip as above / beside each other
+ * on full grids / the best of those once more), keeps the fastest from the fifth pair on -- the reference's
+ * five warm-up queries settle it -- and decides again when the index, a map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
  * rj_lsi_query and a PIP query without an LSI query in flight always use the whole chip.)  The PIP
  * query's inputs must be complete when the call
  * is made; its outputs are complete after rj_sync, rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL). */

@@ -826,7 +826,7 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
   int part = blockIdx.x & 7, tried = 0;
   __shared__ unsigned long long ranges[kPipWaves];  // per wave {end : next}: the unstarted rest of its chunk
   if (threadIdx.x < kPipWaves) ranges[threadIdx.x] = 0;
-  if (blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 72) A.next_work_counter[(threadIdx.x - 64) * 32] = 0;  // (see k_lsi)
+  if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;  // (see k_lsi; any block size has these threads)
   __syncthreads();
   for (;;) {  // XCD-aware dynamic chunked scheduling, see next_chunk / next_group
   {

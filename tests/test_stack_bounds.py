@@ -63,6 +63,77 @@ def test_stack_capacities_cover_the_worst_case(top):
         assert _simulate(top, 64, True, budget)[0] == 64 + 126 * (top - 1)
 
 
+def _simulate_partial(top, k_top, pop_two, fanout, rng, steps):
+    """The same disciplines with ARBITRARY subsets of the children pushed (what the per-lane culling
+    produces): a node of level l > 1 pushes between 0 and `fanout` children.  Returns the peak, which
+    must stay below the all-children closed form scaled to this fanout."""
+    stack = [top] * k_top
+    peak = len(stack)
+    for _ in range(steps):
+        if not stack:
+            break
+        popped = [stack.pop()]
+        if pop_two and stack:
+            popped.append(stack.pop())
+        for lvl in popped:
+            if lvl > 1:
+                stack.extend([lvl - 1] * rng.randint(0, fanout))
+            peak = max(peak, len(stack))
+    return peak
+
+
+def _exhaustive_partial(top, k_top, pop_two, fanout):
+    """Adversary search (small fanout): the largest stack any sequence of child-subset sizes can reach.
+    State = the stack as a tuple of levels; every node of level > 1 may push 0..fanout children."""
+    import functools
+
+    @functools.lru_cache(maxsize=None)
+    def worst(stack):
+        if not stack:
+            return 0
+        st = list(stack)
+        popped = [st.pop()]
+        if pop_two and st:
+            popped.append(st.pop())
+        best = len(st)
+        # choose the pushes of the popped entries one after the other
+        def rec(i, cur):
+            nonlocal best
+            if i == len(popped):
+                best = max(best, len(cur), worst(tuple(cur)))
+                return
+            if popped[i] <= 1:
+                rec(i + 1, cur)
+                return
+            for k in range(fanout + 1):
+                nxt = cur + [popped[i] - 1] * k
+                best = max(best, len(nxt))
+                rec(i + 1, nxt)
+        rec(0, st)
+        return best
+    return max(k_top, worst(tuple([top] * k_top)))
+
+
+@pytest.mark.parametrize("pop_two", [False, True])
+def test_partial_child_subsets_stay_below_the_bound(pop_two):
+    """The closed forms assume every child is pushed; the kernels push arbitrary SUBSETS (per-lane culling,
+    refine masks), and k_lsi's two-pops-per-step discipline then mixes levels on the stack.  The bound
+    k_top + (fanout - 1 | 2 fanout - 2) (top - 1) must hold for every subset choice: exhaustively for
+    fanout 2 (and 3 on shallow trees), by random search for fanout 3-5 and for the real fanout 64."""
+    import random
+    per = (lambda f: 2 * f - 2) if pop_two else (lambda f: f - 1)
+    for fanout, top, k_top in ((2, 2, 2), (2, 3, 2), (2, 4, 2), (2, 4, 1), (3, 2, 3), (3, 3, 2)):
+        assert _exhaustive_partial(top, k_top, pop_two, fanout) <= k_top + per(fanout) * (top - 1)
+    rng = random.Random(7)
+    for fanout in (3, 4, 5, 64):
+        for top in (2, 3, 4, 5):
+            bound = fanout + per(fanout) * (top - 1)
+            for _ in range(40 if fanout < 64 else 6):
+                assert _simulate_partial(top, fanout, pop_two, fanout, rng, 20000) <= bound
+    c = _consts()
+    assert 64 + per(64) * (c["kMaxTop"] - 1) <= (c["kStackEntries"] if pop_two else c["kPipStack"])
+
+
 def test_lds_budget_keeps_the_occupancy():
     """k_lsi: stack + 2 x 128 pair buffers per wave; k_pip: 16-byte entries + candidate lists
     (+ the block's four 8-byte chunk ranges).
