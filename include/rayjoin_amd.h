@@ -212,7 +212,8 @@ typedef enum {
   RJ_T_BUILD_KEYS = 6,
   RJ_T_BUILD_SORT = 7,
   RJ_T_BUILD_LEAVES = 8,
-  RJ_T_BUILD_LEVELS = 9
+  RJ_T_BUILD_LEVELS = 9,
+  RJ_T_PIP_WALK = 10  /* k_pip_walk, the integer-only first pass of the last rj_pip_query* (RJ_T_PIP_KERNEL spans both passes) */
 } rj_timer;
 /* HIP-event time (ms) of the last launch of that stage on the handle's stream; syncs. */
 int rj_last_ms(rj_handle h, int which, float* ms);

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RAYJOIN_AMD_LIB") or os.path.join(HERE, "librayjoin_a
 
 RJ_OK, RJ_E_INVALID, RJ_E_HIP, RJ_E_OVERFLOW, RJ_E_NOMEM, RJ_E_INTERNAL = 0, 1, 2, 3, 4, 5
 RJ_T_BUILD, RJ_T_LSI_KERNEL, RJ_T_PIP_KERNEL, RJ_T_LSI_POINTS, RJ_T_SORT, RJ_T_ORDER = 0, 1, 2, 3, 4, 5
-RJ_T_BUILD_KEYS, RJ_T_BUILD_SORT, RJ_T_BUILD_LEAVES, RJ_T_BUILD_LEVELS = 6, 7, 8, 9
+RJ_T_BUILD_KEYS, RJ_T_BUILD_SORT, RJ_T_BUILD_LEAVES, RJ_T_BUILD_LEVELS, RJ_T_PIP_WALK = 6, 7, 8, 9, 10
 MISS_EID = 0xFFFFFFFF
 
 XSECT_DTYPE = np.dtype(

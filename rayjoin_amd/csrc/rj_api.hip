@@ -37,6 +37,7 @@ struct BvhState {
   int32_t* sface = nullptr;
   QBox* box0 = nullptr;
   int32_t* pmx1 = nullptr;
+  uint2* xtab = nullptr;
   uint32_t* occ = nullptr;
   QBox* lvl[kMaxLevels] = {nullptr};  // boxes of level l, then one sibling-order word per node (rj_device.h)
   uint64_t nlvl[kMaxLevels] = {0};
@@ -53,7 +54,7 @@ struct GridState {  // -mode=grid: one CSR per map (rj_grid.hip)
   uint64_t total = 0;
 };
 
-constexpr int kNumTimers = 10;
+constexpr int kNumTimers = 11;
 // average (w + h) of a 64-query group's quantised box above which the query set is re-ordered
 // along the Morton curve before the kernels run (the domain is 2^31 wide per axis)
 constexpr unsigned long long kIncoherentExtent = 1ull << 28;
@@ -88,7 +89,8 @@ struct rj_handle_s {
   // ratio of the two sides' solo times seen in the "taking turns" trial, (k_lsi + k_lsi_points) / k_pip --
   // measured optima: ratio 0.41 (headline pair) -> 320 + 1280 blocks, 0.72 (nested pair, WaterBodies) -> 576 + 1024
   float co_ratio = 0.41f;
-  int lsi_share_blocks() const { int b = ((int) (780.0f * co_ratio * (float) cus / 256.0f) + 32) / 64 * 64; return b < cus * 3 / 4 ? cus * 3 / 4 : (b > cus * 9 / 4 ? cus * 9 / 4 : b); }
+  int lsi_share_set = 0, pip_share_set = 0;  // "lsi_share_set" / "pip_share_set": fixed grids for schedule 1 (0 = derive them, the default)
+  int lsi_share_blocks() const { if (lsi_share_set) return lsi_share_set; int b = ((int) (780.0f * co_ratio * (float) cus / 256.0f) + 32) / 64 * 64; return b < cus * 3 / 4 ? cus * 3 / 4 : (b > cus * 9 / 4 ? cus * 9 / 4 : b); }
   int pip_share_blocks() const { return lsi_share_blocks() <= cus * 7 / 4 ? cus * 5 : cus * 4; }
   bool aux_pending = false;          // something was enqueued on aux_stream since it was last joined
   hipStream_t stream = nullptr;
@@ -98,6 +100,16 @@ struct rj_handle_s {
   // then three scheduler blocks of 8 counters 128 B apart: LSI, PIP on the main stream, PIP on aux
   unsigned long long* d_counter = nullptr;
   int flip_lsi = 0, flip_pip[2] = {0, 0};  // which of the two counter sets the next launch uses (LSI; PIP on main / aux stream)
+  // PIP in two passes (rj_kernels.hip, k_pip_walk): the integer-only walk settles what it can, k_pip takes the rest
+  int pip_walk = 1;                        // "pip_walk": 1 auto (default), 0 k_pip alone, 2 always both passes
+  int flip_walk[2] = {0, 0};
+  uint32_t* rest[2] = {nullptr, nullptr};  // per stream (main / aux): points the walk left to k_pip (grow-only)
+  uint64_t rest_cap[2] = {0, 0};
+  uint32_t* todo[2] = {nullptr, nullptr};  // per stream: candidate lists the walk left to k_pip_exact, one slot per query position (grow-only)
+  unsigned long long* todo_mask[2] = {nullptr, nullptr};  // ... and which slots of a group are filled
+  unsigned long long* h_rest = nullptr;    // mapped host words [2]: the rest count of the last finished query per stream (a hint
+  unsigned long long* d_rest = nullptr;    // for the next launch's grid and for "pip_rest"; the same memory as the device sees it)
+  uint64_t walk_n[2] = {0, 0};             // size of the query the hint belongs to
   size_t count_word = 0;                   // where the latest LSI query's result count lives
   unsigned long long* d_stats = nullptr;    // [16]
   unsigned long long* h_pinned = nullptr;   // [32] pinned read-back area
@@ -177,14 +189,14 @@ void free_grid(GridState& g) {
 }
 
 void free_bvh(BvhState& b) {
-  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.occ);
+  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
 
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
-  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.occ = b.occ;
+  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.occ = b.occ;
   for (int l = 0; l < kMaxLevels; l++) { d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l]; }
   d.top = b.top; d.n0 = b.n0;
   return d;
@@ -260,7 +272,9 @@ constexpr size_t kSchedBlockWords = 8 * 128 / 8 + 16;            // one schedule
 // launch uses one and clears the other for the next launch on that stream, so no fill kernel sits between
 // the host's call and the kernel (each cost the step 6-8 us of launch gap).
 constexpr size_t kSchedLsi = 16, kSchedPipMain = kSchedLsi + 2 * kSchedBlockWords, kSchedPipAux = kSchedPipMain + 2 * kSchedBlockWords;
-constexpr size_t kCounterBytes = (kSchedPipAux + 2 * kSchedBlockWords) * 8;
+constexpr size_t kSchedWalkMain = kSchedPipAux + 2 * kSchedBlockWords, kSchedWalkAux = kSchedWalkMain + 2 * kSchedBlockWords;
+constexpr size_t kCounterBytes = (kSchedWalkAux + 2 * kSchedBlockWords) * 8;
+constexpr size_t kRestCountWord = 8;     // [8],[9] main stream (alternating), [10],[11] aux: how many points k_pip_walk left to k_pip
 constexpr size_t kGridLsiCountWord = 6;  // rj_lsi_query_grid's result count (cleared by a fill: not on the hot path)
 
 // after a stream sync: did a traversal stack overflow?  (cannot for an index rj_build_lbvh accepted)
@@ -298,12 +312,16 @@ int rj_create(int device_id, rj_handle* out) {
             hipMalloc((void**) &h->d_stats, 128) == hipSuccess &&
             hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess &&
             hipHostMalloc((void**) &h->h_fault, 64, hipHostMallocMapped) == hipSuccess &&
-            hipHostGetDevicePointer((void**) &h->d_fault, h->h_fault, 0) == hipSuccess;
+            hipHostGetDevicePointer((void**) &h->d_fault, h->h_fault, 0) == hipSuccess &&
+            hipHostMalloc((void**) &h->h_rest, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**) &h->d_rest, h->h_rest, 0) == hipSuccess;
   if (ok) {
     h->h_fault[0] = h->h_fault[1] = 0;
+    h->h_rest[0] = h->h_rest[1] = ~0ull;  // (no finished two-pass query yet)
     ok = hipMemset(h->d_counter, 0, kCounterBytes) == hipSuccess;
     for (size_t blk : {kSchedLsi, kSchedLsi + kSchedBlockWords, kSchedPipMain, kSchedPipMain + kSchedBlockWords, kSchedPipAux,
-                       kSchedPipAux + kSchedBlockWords})  // behind each block's counters: where its kernel reports a fault
+                       kSchedPipAux + kSchedBlockWords, kSchedWalkMain, kSchedWalkMain + kSchedBlockWords, kSchedWalkAux,
+                       kSchedWalkAux + kSchedBlockWords})  // behind each block's counters: where its kernel reports a fault
       ok = ok && hipMemcpy((char*) (h->d_counter + blk) + kSchedFaultPtrWord * 4, &h->d_fault, sizeof(h->d_fault), hipMemcpyHostToDevice) == hipSuccess;
   }
   for (int t = 0; ok && t < kNumTimers; t++)
@@ -321,6 +339,7 @@ int rj_destroy(rj_handle h) {
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
   for (int k = 0; k < 2; k++) for (int i = 0; i < 2; i++) (void) hipFree(h->ordc[k][i].perm);
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
+  (void) hipHostFree(h->h_rest); (void) hipFree(h->rest[0]); (void) hipFree(h->rest[1]); (void) hipFree(h->todo[0]); (void) hipFree(h->todo[1]); (void) hipFree(h->todo_mask[0]); (void) hipFree(h->todo_mask[1]);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
   (void) hipFree(h->arena);
@@ -372,6 +391,9 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_concurrent")) *value = h->pip_concurrent;
   else if (!strcmp(name, "pip_schedule")) *value = h->pip_concurrent == 2 ? h->co_choice : (h->pip_concurrent == 1 ? 1 : 0);
   else if (!strcmp(name, "pip_schedule_trials")) *value = h->co_trials;
+  else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
+  else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
+  else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
   else if (!strcmp(name, "pip_share_blocks")) *value = h->pip_share_blocks();
   else return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
@@ -388,6 +410,16 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "pip_concurrent: 0 never, 1 LSI and PIP queries come in pairs and share the chip, 2 the same if it measures faster");
     h->pip_concurrent = (int) value;
     co_reset(h);
+    return RJ_OK;
+  }
+  if (!strcmp(name, "pip_walk")) {
+    if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "pip_walk: 0 k_pip alone, 1 auto, 2 always two passes");
+    h->pip_walk = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "lsi_share_set") || !strcmp(name, "pip_share_set")) {  // (tuning / tools: the grids of schedule 1)
+    if (value < 0 || value > (1 << 20)) return fail(h, RJ_E_INVALID, "%s out of range", name);
+    (name[0] == 'l' ? h->lsi_share_set : h->pip_share_set) = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "query_order")) {
@@ -579,6 +611,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     if (!r) r = dev_alloc(h, &b.sface, b.n0p);
     if (!r) r = dev_alloc(h, &b.box0, b.n0p);
     if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
+    if (!r) r = dev_alloc(h, &b.xtab, b.n0p);
     if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
     for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l] + b.alloc[l] / 2);  // 16 B box + 8 B order word per node
     if (r) { free_bvh(b); return r; }
@@ -602,7 +635,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     tic(h, RJ_T_BUILD_LEAVES);
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p / 64, b.alloc[1],
-                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.lvl[1], b.occ)) != hipSuccess) break;
+                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
     const QBox* child = b.lvl[1];
@@ -868,8 +901,68 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
+  a.rest = nullptr; a.rest_count = nullptr; a.next_rest_count = nullptr; a.n_dev = nullptr;
+  a.todo = nullptr; a.todo_mask = nullptr;
+  // (k_pip_walk keeps 8 blocks per CU resident where k_pip keeps 6: the shared schedule leaves k_lsi the same room)
+  const int walk_full = h->cus * pip_walk_blocks_per_cu(h->bvh[base_map_id].top);
+  int walk_blocks = h->max_blocks;
+  if (aux && h->lsi_shared) {
+    const int share = h->pip_share_set ? h->pip_share_set : walk_full - h->cus;
+    walk_blocks = share < h->max_blocks ? share : h->max_blocks;
+  }
+  // Two passes unless instrumented: k_pip_walk (integer tests only, 8 waves per SIMD) settles every point whose
+  // answer is a single certain hit and lists the others; k_pip, the exact kernel, locates those from scratch
+  // right behind it, reading the count on the device.  "auto" drops the first pass for a query size whose
+  // last run left more than 30 % of its points over (the hint arrives through mapped host memory).
+  const int si = aux ? 1 : 0;
+  // (instrumented: k_pip alone, unless "pip_walk" 2 asks for the walk's own counters)
+  bool walk = h->pip_walk != 0 && (!h->stats_on || h->pip_walk == 2) && n > 0 && n < (1ull << 32);
+  if (walk && h->pip_walk == 1 && h->walk_n[si] == n && h->h_rest[si] != ~0ull && h->h_rest[si] * 10 > n * 3) walk = false;
+  if (walk && h->rest_cap[si] < n) {
+    RJ_HIP(h, hipStreamSynchronize(st));  // (the lists may still be in use by a query in flight)
+    (void) hipFree(h->rest[si]); (void) hipFree(h->todo[si]); (void) hipFree(h->todo_mask[si]);
+    h->rest[si] = nullptr; h->rest_cap[si] = 0; h->todo[si] = nullptr; h->todo_mask[si] = nullptr;
+    if (int r = dev_alloc(h, &h->rest[si], n)) return r;
+    if (int r = dev_alloc(h, &h->todo[si], n * (uint64_t) pip_walk_list_slots())) return r;
+    if (int r = dev_alloc(h, &h->todo_mask[si], n / 4 + 1)) return r;  // (groups of >= 4 points)
+    h->rest_cap[si] = n;
+  }
   tic(h, RJ_T_PIP_KERNEL, st);
-  if (n) {
+  if (n && walk) {
+    const int wflip = h->flip_walk[si];
+    PipArgs w = a;
+    w.work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + wflip * kSchedBlockWords);
+    w.next_work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + (1 - wflip) * kSchedBlockWords);
+    w.rest = h->rest[si];
+    w.rest_count = h->d_counter + kRestCountWord + 2 * si + wflip;
+    w.next_rest_count = h->d_counter + kRestCountWord + 2 * si + (1 - wflip);
+    w.todo = h->todo[si]; w.todo_mask = h->todo_mask[si];
+    if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
+    tic(h, RJ_T_PIP_WALK, st);
+    RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
+    toc(h, RJ_T_PIP_WALK, st);
+    h->flip_walk[si] = 1 - wflip;
+    RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8));
+    // second pass over what is left: the grid follows the last count seen for this query size
+    a.order = h->rest[si];
+    a.n_dev = w.rest_count;
+    a.rest_count = h->d_rest + si;  // (k_pip reports the count it found to the host)
+    // (the list is appended group by group all over the map: the fewer points it holds, the less a wave's points have
+    //  to do with each other -- a handful of overflowed lists are unrelated traversals, one wave each)
+    const uint64_t seen = h->walk_n[si] == n && h->h_rest[si] != ~0ull ? h->h_rest[si] : 8192;
+    a.group_lanes = seen < 8192 ? 1 : (seen * 100 < n ? 4 : (seen * 10 < n ? 8 : 16));
+    a.chunk_groups = 1;
+    a.stats = nullptr;
+    int rest_blocks = max_blocks;
+    if (h->walk_n[si] == n && h->h_rest[si] != ~0ull) {
+      const uint64_t want = h->h_rest[si] / (a.group_lanes * 4 * 2) + 1;  // about two groups per wave
+      const uint64_t floor_blocks = (uint64_t) h->cus;
+      rest_blocks = (int) (want < floor_blocks ? floor_blocks : (want > (uint64_t) max_blocks ? (uint64_t) max_blocks : want));
+    }
+    h->walk_n[si] = n;
+    RJ_HIP(h, launch_pip(st, a, false, rest_blocks));
+    h->flip_pip[si] = 1 - pflip;
+  } else if (n) {
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
     h->flip_pip[aux ? 1 : 0] = 1 - pflip;
   }

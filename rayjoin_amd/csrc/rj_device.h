@@ -76,6 +76,10 @@ struct DeviceBvh {
   const int32_t* sface;   // [n0p] face below each segment (get_face_id, src/map/map.h:79-87)
   const QBox* box0;       // [n0p] per-segment boxes (padding = empty); sorted by x0 inside each 64-block
   const int32_t* pmx1;    // [n0p] prefix max of box x1 inside each 64-block
+  const uint2* xtab;      // [n0p] per 64-block: 256 x-buckets (leaf_bucket_shift), two bytes each -- lane l holds buckets 4l..4l+3:
+                          // .x byte k = slots of the block whose x0 lies in a bucket <= 4l+k (the scan of a point in that
+                          // bucket starts below this slot), .y byte k = slots whose prefix-max x1 ends before the bucket
+                          // (where the scan stops): the candidates of a point, without a search and without a stop test
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
   // Behind the boxes of every level l (at lvl[l] + pad64(nlvl[l])) sits one 64-bit word per node:
@@ -86,6 +90,13 @@ struct DeviceBvh {
   uint64_t n0;            // real segment count
 };
 
+// x-buckets of a leaf block (k_pip_walk): 256 buckets of 2^shift quanta from the block's x0, the smallest
+// power of two that covers its x-extent.  Build (k_build_leaves) and query derive the shift from the same
+// level-1 box, so a point's bucket is comparable with the segments' buckets: monotone in x.
+__host__ __device__ __forceinline__ int leaf_bucket_shift(uint32_t extent_minus_1) {
+  if (extent_minus_1 < 256u) return 0;
+  return 24 - __builtin_clz(extent_minus_1);  // (extent_minus_1 >> shift) < 256
+}
 __device__ __forceinline__ const uint64_t* sibling_order(const DeviceBvh& T, int l) {
   return reinterpret_cast<const uint64_t*>(T.lvl[l] + (((uint64_t) T.nlvl[l] + 63) & ~(uint64_t) 63));
 }

@@ -47,6 +47,16 @@ struct PipArgs {
   uint32_t group_lanes;  // points per wave (0 = choose from the point count)
   int stack_cap;         // instrumented kernel only: use fewer stack entries (tests of the fault path)
   unsigned long long* stats;
+  // k_pip_walk hand-over.  A point the walk could not settle with integer tests alone leaves its complete candidate
+  // list in `todo` (one 16-byte slot per query POSITION, a 64-bit mask per group says which are filled: no atomics,
+  // no capacity to run out of) and k_pip_exact evaluates it, no traversal; a point whose list overflowed goes to
+  // `rest` and k_pip locates it from scratch (order = rest, n_dev = the count as the walk left it on the device).
+  uint32_t* todo;                        // [n][pip_walk_list_slots()] sorted slots of the index, 0xFFFFFFFF = unused (walk, k_pip_exact)
+  unsigned long long* todo_mask;         // [groups] (walk, k_pip_exact)
+  uint32_t* rest;                        // [n] (walk only)
+  unsigned long long* rest_count;        // (walk) zero when the kernel starts; (k_pip) nullable: where it reports the count it found
+  unsigned long long* next_rest_count;   // (walk) the next walk's counter on this stream: cleared by this walk
+  const unsigned long long* n_dev;       // (k_pip only) nullable: process min(n, *n_dev) queries
 };
 
 // ---- -mode=grid on the device (rj_grid.hip) ------------------------------------------------
@@ -97,7 +107,7 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, QBox* lvl1, uint32_t* occ);
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ);
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
@@ -109,5 +119,10 @@ hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, co
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
                              uint64_t n, const unsigned long long* n_dev, XsectRec* out);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
+hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
+hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks);
+int pip_walk_list_slots();  // candidates a todo record holds
+uint32_t pip_walk_group_lanes(uint64_t n, int top, int cus);  // points per wave k_pip_walk uses when the caller leaves it open
+int pip_walk_blocks_per_cu(int top);  // resident 256-thread blocks of k_pip_walk per compute unit for a tree of this height
 
 }  // namespace rj

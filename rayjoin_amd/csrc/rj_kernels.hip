@@ -190,9 +190,10 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       uint64_t nblocks, uint64_t n_parent_alloc,
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
-                                                      int32_t* __restrict__ pmx1, QBox* __restrict__ lvl1,
-                                                      uint32_t* __restrict__ occ) {
+                                                      int32_t* __restrict__ pmx1, uint2* __restrict__ xtab,
+                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ) {
   __shared__ int32_t sx1[4][64];
+  __shared__ uint4 hist[4][64];  // 256 x-bucket counters per wave
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
@@ -241,6 +242,42 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     wave_lds_fence();
     const int32_t ux0 = wave_min(b.x0), uy0 = wave_min(b.y0), ux1 = wave_max(b.x1), uy1 = wave_max(b.y1);
     if (lane == 0) lvl1[blk] = QBox{ux0, uy0, ux1, uy1};
+    // x-bucket table (k_pip_walk): 256 buckets over the block's x-extent.  The block is x0-sorted, so the segments
+    // that can contain a point of bucket b in x are the slots [lo_b, hi_b): hi_b = how many segments START in a
+    // bucket <= b, lo_b = how many have a prefix-max x1 that ENDS before bucket b (the prefix max is monotone, so
+    // those are the first slots).  Two histograms + two prefix sums; the point's scan needs no search for its
+    // first slot and no prefix-max fetch to know its last.
+    {
+      const int sh = leaf_bucket_shift((uint32_t) (ux1 - ux0));
+      uint32_t* hw = reinterpret_cast<uint32_t*>(&hist[wib][0]);
+      uint32_t packed[2];
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {
+        hist[wib][lane] = make_uint4(0, 0, 0, 0);
+        wave_lds_fence();
+        // pass 0: by the bucket of x0 (this lane's own segment); pass 1: by the bucket of the prefix max of slot `lane`
+        // (padding slots sort last and count in neither: a point never scans them)
+        const bool use = pass == 0 ? valid : (uint64_t) blk * 64 + lane < ne;
+        const int32_t v = pass == 0 ? b.x0 : m;
+        if (use) atomicAdd(&hw[(uint32_t) (v - ux0) >> sh], 1u);
+        wave_lds_fence();
+        const uint4 c = hist[wib][lane];
+        const uint32_t p0 = c.x, p1 = p0 + c.y, p2 = p1 + c.z, p3 = p2 + c.w;
+        uint32_t inc = p3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t t = __shfl_up(inc, d, 64);
+          if (lane >= d) inc += t;
+        }
+        const uint32_t exc = inc - p3;
+        // pass 0: inclusive counts (bucket <= b); pass 1: exclusive counts (bucket < b)
+        packed[pass] = pass == 0 ? (exc + p0) | ((exc + p1) << 8) | ((exc + p2) << 16) | ((exc + p3) << 24)
+                                 : exc | ((exc + p0) << 8) | ((exc + p1) << 16) | ((exc + p2) << 24);
+        wave_lds_fence();
+      }
+      xtab[blk * 64 + lane] = make_uint2(packed[0], packed[1]);
+      wave_lds_fence();
+    }
   }
 }
 
@@ -813,7 +850,15 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
   const int wib = threadIdx.x >> 6;
   PipWaveLds& L = lds[wib];
   const uint32_t GL = A.group_lanes;  // points per wave: 64, or fewer for small query sets
-  const uint64_t ngroups = (A.n + GL - 1) / GL;
+  // (behind k_pip_walk: the queries are the points it left over, counted on the device)
+  uint64_t nq = A.n;
+  if (A.n_dev) {
+    const unsigned long long left = __hip_atomic_load(A.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nq = left < nq ? left : nq;
+    // (the host sizes the next launch's grid by this count: mapped host memory, a plain store)
+    if (A.rest_count && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.rest_count, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
   const int qm = A.query_map_id;
   const int stack_cap = STATS && A.stack_cap < kPipStack ? A.stack_cap : kPipStack;  // (lowered only by tests of the fault path, instrumented kernel)
@@ -837,7 +882,7 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
     const uint64_t g = g32;
     const long long tkg = STATS ? clock64() : 0;
     const uint64_t ipos = g * GL + lane;  // position in the (possibly Morton-sorted) query order
-    const bool valid = (uint32_t) lane < GL && ipos < A.n;
+    const bool valid = (uint32_t) lane < GL && ipos < nq;
     const uint64_t ip = A.order ? (valid ? A.order[ipos] : 0) : ipos;
     // The traversal works on the quantised point; the exact coordinates are read again (an L2 hit)
     // by the few lanes whose candidates need the exact arithmetic -- 0.2 per group on the headline
@@ -1065,6 +1110,334 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
   }
 }
 
+
+// =============================================================================================
+// PIP, first pass: k_pip_walk -- the same front-to-back traversal as k_pip with everything that is
+// not integer work taken out, so that it fits 64 VGPRs and (stack sized by the tree's height) 20 KiB of
+// LDS per block: 8 waves per SIMD instead of 6.  k_pip's time is t = 0.39 ms + 3.83 ms / (waves per SIMD)
+// on the headline pair (tools/sweep.py --opt max_blocks): per-wave latency, not VALU throughput
+// (tools/issue_probe.hip: a SIMD issues a wave-instruction every 0.7-2 cycles with 6-8 waves; k_pip used
+// one in 4.9), so both more waves and fewer instructions / LDS round trips per leaf visit pay.
+//   * A point whose candidate list ends up holding exactly one CERTAIN hit (or nothing) is settled here:
+//     99.7 % of the headline's points.  Every other point -- ties, points on base vertices, boxes that
+//     touch the ray's x or start below the point -- leaves with its complete candidate list (WalkTodo) and
+//     k_pip_exact evaluates that list with the exact arithmetic, no second traversal; only a point whose
+//     list overflowed goes to the `rest` list, which k_pip locates from scratch (order = rest, n from the device).
+//   * Leaf search without a search: the block's 256-entry x-bucket table (k_build_leaves) gives the slot
+//     the backward scan starts at -- one cross-lane read instead of 7 pivots + 4 dependent probes.
+// Pruning is exactly k_pip's (certain hits bound a lane; a certain hit below the held one replaces it),
+// so whatever is settled here is what k_pip would have answered.
+// =============================================================================================
+#ifndef RJ_WALK_LIST
+#define RJ_WALK_LIST 6
+#endif
+constexpr int kWalkList = RJ_WALK_LIST;  // candidate slots per lane (the todo record holds as many); a lane that needs more goes to the rest list
+__host__ __device__ __forceinline__ int walk_stack_entries(int top) { return 64 + 63 * (top > 1 ? top - 1 : 0) + 3; }
+__host__ __device__ __forceinline__ size_t walk_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256; }
+
+template <bool STATS>
+__global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
+  extern __shared__ uint4 walk_smem[];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  const DeviceBvh& T = A.bvh;
+  const int stack_cap = walk_stack_entries(T.top);
+  uint4* const stack = walk_smem + (size_t) wib * (walk_wave_lds(T.top) / 16);
+  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [kWalkList][64], bank = lane
+  const uint32_t GL = A.group_lanes;
+  const uint64_t ngroups = (A.n + GL - 1) / GL;
+  const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
+  int part = blockIdx.x & 7, tried = 0;
+  unsigned long long st_leaf = 0, st_nodes = 0, st_box = 0, st_stale = 0, st_rest = 0, st_leaf_lanes = 0;
+  long long tk_leaf = 0, tk_node = 0, tk_sched = 0, tk_head = 0, tk_tail = 0;  // STATS: cycle stamps
+  const long long tk_begin = STATS ? clock64() : 0;
+  __shared__ unsigned long long ranges[4];
+  if (threadIdx.x < 4) ranges[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;  // (see k_lsi)
+  if (blockIdx.x == 0 && threadIdx.x == 8) *A.next_rest_count = 0;
+  __syncthreads();
+  for (;;) {
+    uint32_t g32 = 0;
+    const long long tks = STATS ? clock64() : 0;
+    if (!next_group<4>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
+    if (STATS) tk_sched += clock64() - tks;
+    const long long tkg = STATS ? clock64() : 0;
+    const uint64_t ipos = (uint64_t) g32 * GL + lane;
+    const bool valid = (uint32_t) lane < GL && ipos < A.n;
+    const uint32_t ip = A.order ? (valid ? A.order[ipos] : 0u) : (uint32_t) ipos;
+    int32_t qx = 0, qy = 0;
+    if (valid) {
+      typedef long long ll2_t __attribute__((ext_vector_type(2)));
+      const ll2_t p = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip);
+      qx = quant(p.x);
+      qy = quant(p.y);
+    }
+    const int32_t qym1 = qy > 0 ? qy - 1 : 0;
+    const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
+    const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
+    const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
+    int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer (-1: the lane sits out)
+    int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
+    // This lane's candidate list is cand[lane + 64 k] (bank = lane); `cand_at` = where the next one goes, so the fill
+    // is (cand_at - lane) / 64 and kWalkList + 1 fills mean "overflowed: the rest list takes the point".
+    const uint32_t cand_base = (uint32_t) lane;
+    uint32_t cand_at = cand_base;
+    int32_t sure_y0 = INT32_MIN;  // the list holds exactly one candidate, a certain hit whose box starts here (INT32_MIN: it does not)
+
+    auto refine_if_many = [&](const QBox& b, uint64_t um) -> uint64_t {
+      if (__popcll(um) <= kPipRefineAbove) return um;
+      uint64_t keep = 0;
+      while (um) {
+        const int c = __builtin_ctzll(um);
+        um &= um - 1;
+        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
+        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
+        if (__ballot(ray_can_hit(qx, qym1, qbest, cx0, cy0, cx1, cy1))) keep |= 1ull << c;
+      }
+      return keep;
+    };
+    int sp = 0;
+    {
+      const QBox b = T.lvl[T.top][lane];
+      const uint64_t higher = sibling_order(T, T.top)[lane];
+      uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
+      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+      if ((m >> lane) & 1)
+        stack[__popcll(m & higher)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
+      sp = __popcll(m);
+      wave_lds_fence();
+    }
+    if (STATS) tk_head += clock64() - tkg;
+    while (sp > 0) {
+      // every lane reads the same entry (an LDS broadcast): the staleness test runs on those registers as they
+      // are, only the node id moves to the scalar side
+      const uint4 ent = stack[sp - 1];
+      --sp;
+      const int32_t ey0 = (int32_t) ent.y, ex0 = (int32_t) ent.z, ex1 = (int32_t) ent.w;
+      const bool want = ((qx - ex0) | (ex1 - qx) | (qbest - ey0)) >= 0;  // stale entries die here, untouched
+      if (!__ballot(want)) {
+        if (STATS) st_stale++;
+        continue;
+      }
+      const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
+      const long long tk0 = STATS ? clock64() : 0;
+      const int lvl = (int) (e >> 28);
+      const uint32_t idx = e & 0x0FFFFFFFu;
+      if (lvl > 1) {
+        const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
+        const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane];
+        uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+        if ((m >> lane) & 1)
+          stack[sp + __popcll(m & higher)] =
+              make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
+        sp += __popcll(m);
+        wave_lds_fence();
+        if (STATS) {
+          st_nodes++;
+          tk_node += clock64() - tk0;
+        }
+      } else {
+        const uint32_t slot0 = idx * 64;
+        const QBox bb = T.box0[(uint64_t) slot0 + lane];  // one base segment per lane, sorted by x0
+        const uint2 tab = T.xtab[(uint64_t) slot0 + lane];
+        // The block's bucket table gives the slots [lo, hi) that can contain this point's x: no search for the
+        // first one, no prefix-max fetch to know the last (the entry carries the block's x-extent, which is what
+        // the table was built on).
+        const uint32_t sx0s = __builtin_amdgcn_readfirstlane((uint32_t) ex0);
+        const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
+        const uint32_t bk = want ? ((uint32_t) qx - sx0s) >> sh : 0u;
+        const uint32_t bsh = (bk & 3u) * 8u;
+        const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+        const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+        // One correction per end (both fetches in one round trip): the range is exact to a bucket, and with ~28 lanes
+        // looking, some lane's bucket nearly always holds a vertex -- a slot that starts behind the point, or one
+        // that ends before it -- which would cost the whole wave an iteration each.
+        int j = (int) hi - 1, jlo = (int) lo;
+        {
+          const int32_t top_x0 = __builtin_amdgcn_ds_bpermute(j << 2, bb.x0);
+          const int32_t low_x1 = __builtin_amdgcn_ds_bpermute(jlo << 2, bb.x1);
+          j -= top_x0 > qx ? 1 : 0;
+          jlo += low_x1 < qx ? 1 : 0;  // (slots below lo end before the bucket, so slot lo's prefix max is its own x1)
+        }
+        j = want ? j : -1;
+        jlo = want ? jlo : 0;
+        const int32_t qbest_before = qbest;
+        if (STATS) {
+          st_leaf++;
+          st_leaf_lanes += (unsigned long long) __popcll(__ballot(want));
+        }
+        while (__ballot(j >= jlo)) {
+          const int jj = j & 63;  // (a lane past its range reads some slot: harmless, the test below fails on j - jlo)
+          const int ja = j << 2;  // (ds_bpermute takes the lane from bits 7:2 of the address)
+          const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, bb.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, bb.x1);
+          const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, bb.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, bb.y1);
+          if (STATS) st_box++;
+          // ray_can_hit and "still inside my range" as one sign test
+          if (((qx - sx0) | (sx1 - qx) | (sy1 - qym1) | (qbest - sy0) | (j - jlo)) >= 0) {
+            // certain hit (strictly inside in x, strictly above) => its box top bounds the answer; one that ends below
+            // the start of the one certain hit held so far replaces it (that one is certainly higher)
+            const bool certain = sx0 < qx && qx < sx1 && sy0 > qy;
+            const bool replace = certain && sy1 < sure_y0;
+            const bool first = cand_at == cand_base;
+            // (a fifth candidate overwrites slot 0 of a list that is abandoned anyway: fill 5 = "the rest list takes
+            // this point", and the lane sits the rest of the traversal out)
+            const bool over = !replace && cand_at == cand_base + kWalkList * 64;
+            cand[(replace || over) ? cand_base : cand_at] = slot0 + (uint32_t) jj;
+            sure_y0 = (replace || (first && certain)) ? sy0 : INT32_MIN;
+            cand_at += replace ? 0u : 64u;
+            const int32_t top = certain ? sy1 + 1 : 0x7FFFFFFF;
+            qbest = over ? -1 : (top < qbest ? top : qbest);
+          }
+          j--;
+        }
+        if (__ballot(qbest != qbest_before)) {
+          const int32_t gbest_before = gbest;
+          gbest = wave_max(qbest);
+          if (gbest < gbest_before && sp > 1) {  // sweep the stack once: drop every entry that starts above the group's bound
+            int kept = 0;
+            for (int base = 0; base < sp; base += 64) {
+              const int i = base + lane;
+              const bool have = i < sp;
+              uint4 en = make_uint4(0, 0, 0, 0);
+              if (have) en = stack[i];
+              const bool alive = have && (int32_t) en.y <= gbest;
+              const uint64_t am = __ballot(alive);
+              wave_lds_fence();
+              if (alive) stack[kept + rank_below(am)] = en;
+              kept += __popcll(am);
+            }
+            if (STATS) st_stale += (unsigned long long) (sp - kept);
+            sp = kept;
+            wave_lds_fence();
+          }
+        }
+        if (STATS) tk_leaf += clock64() - tk0;
+      }
+    }
+    const long long tkt = STATS ? clock64() : 0;
+    // settled: nothing above the point, or exactly one candidate and it is a certain hit (every other
+    // edge over this x was pruned because it starts above that candidate's box top)
+    const bool done = valid && (cand_at == cand_base || sure_y0 != INT32_MIN);
+    if (done) {
+      const bool hit = cand_at != cand_base;
+      const uint32_t slot = hit ? cand[lane] : 0u;
+      __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip);
+      if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip);
+    }
+    // the others leave with their candidate list (the exact kernel needs nothing else: every edge that could be the
+    // answer is on it, pruning only ever used certain hits) -- or, with an overflowed list, as a point for k_pip.
+    // One slot per query position and one mask per group: nothing to contend for (an append counter shared by
+    // 450 k groups, most of which have something to hand over on a map pair with shared vertices, stalls them all).
+    const uint32_t fill = (cand_at - cand_base) >> 6;
+    const bool listed = valid && !done && fill <= (uint32_t) kWalkList;
+    const bool rest = valid && !done && !listed;
+    if (listed) {
+#pragma unroll
+      for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[lane + 64 * k] : 0xFFFFFFFFu;
+    }
+    const uint64_t lm = __ballot(listed);
+    if (lane == 0) A.todo_mask[g32] = lm;
+    const uint64_t rm = __ballot(rest);
+    if (rm) {
+      unsigned long long base = 0;
+      if (lane == 0) base = atomicAdd(A.rest_count, (unsigned long long) __popcll(rm));
+      base = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) base);
+      if (rest) A.rest[base + rank_below(rm)] = ip;
+    }
+    wave_lds_fence();  // (the lists are reused by the next group)
+    if (STATS) {
+      st_rest += (unsigned long long) __popcll(rm);
+      tk_tail += clock64() - tkt;
+    }
+  }
+  if (STATS && lane == 0 && A.stats) {  // (same slots as k_pip's where the meaning is the same)
+    const long long tk_total = clock64() - tk_begin;
+    atomicAdd(&A.stats[0], st_leaf);
+    atomicAdd(&A.stats[1], st_rest);
+    atomicAdd(&A.stats[2], st_nodes);
+    atomicAdd(&A.stats[3], st_box);
+    atomicAdd(&A.stats[4], (unsigned long long) tk_total);
+    atomicAdd(&A.stats[5], (unsigned long long) tk_node);
+    atomicAdd(&A.stats[6], (unsigned long long) tk_leaf);
+    atomicMax(&A.stats[9], (unsigned long long) tk_total);
+    atomicAdd(&A.stats[10], (unsigned long long) tk_sched);
+    atomicAdd(&A.stats[11], (unsigned long long) tk_head);
+    atomicAdd(&A.stats[12], (unsigned long long) tk_tail);
+    atomicAdd(&A.stats[13], st_stale);
+    atomicAdd(&A.stats[15], st_leaf_lanes);
+  }
+}
+
+
+// The walk's leftovers: the exact predicate (pip.h:36-95, as in k_pip's evaluate) over each listed point's complete
+// candidate list.  A wave reads the masks of its share of the groups, compacts the listed positions into an LDS
+// queue (__ballot / mbcnt, like k_lsi's pair buffer) and evaluates 64 of them at a time, one point per lane: on a
+// map pair with shared vertices a quarter of the points arrive here, on the headline pair 0.3 %, and either way
+// the lanes that do the 128-bit arithmetic are all busy.
+__global__ __launch_bounds__(256) void k_pip_exact(PipArgs A) {
+  __shared__ uint32_t queue[4][128];
+  const DeviceBvh& T = A.bvh;
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  const uint32_t gl_shift = 31 - __builtin_clz(A.group_lanes);  // (group_lanes is a power of two)
+  const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+  auto evaluate = [&](uint32_t i) {
+    // everything a point needs is requested before anything is used: the record's slots, then the segments behind
+    // them (a point's evaluation is otherwise a chain of dependent gathers, and this kernel has little else to hide them)
+    const uint64_t ip = A.order ? A.order[i] : i;
+    uint32_t slot[kWalkList];
+#pragma unroll
+    for (int r = 0; r < kWalkList; r++) slot[r] = A.todo[(uint64_t) i * kWalkList + r];
+    const int64_t px = A.pts[2 * ip], py = A.pts[2 * ip + 1];
+    Seg seg[kWalkList];
+#pragma unroll
+    for (int r = 0; r < kWalkList; r++) seg[r] = T.sseg[slot[r] != 0xFFFFFFFFu ? slot[r] : 0u];
+    double best_yy = __builtin_inf();
+    uint32_t best_slot = 0xFFFFFFFFu;
+    Seg best_seg = seg[0];
+#pragma unroll
+    for (int r = 0; r < kWalkList; r++) {
+      double yy;
+      if (slot[r] != 0xFFFFFFFFu && pip_eval_y(seg[r], px, py, A.query_map_id, &yy)) {
+        bool better = yy < best_yy;
+        if (yy == best_yy && best_slot != 0xFFFFFFFFu)  // tie: slope rule, then eid
+          better = pip_better(yy, pip_slope(seg[r]), T.seid[slot[r]], best_yy, pip_slope(best_seg), T.seid[best_slot], A.query_map_id);
+        if (better) {
+          best_yy = yy; best_slot = slot[r]; best_seg = seg[r];
+        }
+      }
+    }
+    const bool hit = best_slot != 0xFFFFFFFFu;
+    A.closest[ip] = hit ? T.seid[best_slot] : 0xFFFFFFFFu;
+    if (A.face) A.face[ip] = hit ? T.sface[best_slot] : 0;
+  };
+  int nq = 0;  // wave-uniform fill of the queue
+  // 16 groups per step: lane l < 16 fetches the mask of group g0 + l (one load, not one round trip per group)
+  const uint64_t ngroups = (A.n + A.group_lanes - 1) >> gl_shift;
+  for (uint64_t g0 = wave * 16; g0 < ngroups; g0 += nwaves * 16) {
+    unsigned long long mine = 0;
+    if (lane < 16 && g0 + lane < ngroups) mine = A.todo_mask[g0 + lane];
+    uint64_t any = __ballot(mine != 0);
+    while (any) {
+      const int k = __builtin_ctzll(any);
+      any &= any - 1;
+      const uint64_t m = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (mine >> 32), k) << 32) |
+                         (uint32_t) __builtin_amdgcn_readlane((int) mine, k);
+      if ((m >> lane) & 1) queue[wib][nq + rank_below(m)] = (uint32_t) (((g0 + k) << gl_shift) + lane);
+      nq += __popcll(m);
+      wave_lds_fence();
+      if (nq >= 64) {
+        evaluate(queue[wib][nq - 64 + lane]);
+        nq -= 64;
+        wave_lds_fence();
+      }
+    }
+  }
+  if (lane < nq) evaluate(queue[wib][lane]);
+}
+
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
@@ -1131,9 +1504,9 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, QBox* lvl1, uint32_t* occ) {
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, lvl1, occ);
+                     left, right, ne, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
   return hipGetLastError();
 }
 
@@ -1220,6 +1593,39 @@ hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, c
   // with a device-side count the grid is sized for a typical result, the loop is grid-stride anyway
   const uint64_t expect = n_dev ? (n < (1u << 20) ? n : (1u << 20)) : n;
   hipLaunchKernelGGL(k_lsi_points, dim3(grid_for(expect, 256, 4096)), dim3(256), 0, st, seg0, seg1, pairs, n, n_dev, out);
+  return hipGetLastError();
+}
+
+int pip_walk_list_slots() { return kWalkList; }
+
+int pip_walk_blocks_per_cu(int top) {
+  const size_t block = 4 * walk_wave_lds(top) + 64;
+  const size_t by_lds = (size_t) 160 * 1024 / block;
+  return (int) (by_lds < 8 ? by_lds : 8);
+}
+
+uint32_t pip_walk_group_lanes(uint64_t n, int top, int cus) { return pick_group_lanes(n, cus * pip_walk_blocks_per_cu(top), 4); }
+
+hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int max_blocks) {
+  PipArgs a = a_in;
+  const size_t lds = 4 * walk_wave_lds(a.bvh.top);
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  const int res = cus * pip_walk_blocks_per_cu(a.bvh.top);
+  if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.n, res, 4);
+  const uint64_t ngroups = (a.n + a.group_lanes - 1) / a.group_lanes;
+  const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+  const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
+  if (stats)
+    hipLaunchKernelGGL(k_pip_walk<true>, dim3(grid), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(k_pip_walk<false>, dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks) {
+  hipLaunchKernelGGL(k_pip_exact, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 

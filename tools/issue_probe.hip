@@ -163,8 +163,7 @@ static void run(int cus, unsigned long long* d_cycles, unsigned int* d_sink) {
     const double per_wave = (double) REPS * 8 * kPerBlock[OP];  // instructions (or pairs) per wave
     // cycles per instruction per SIMD = mean wave lifetime / (instructions of the wps waves sharing the SIMD)
     printf(" %6.2f", sum / cyc.size() / (per_wave * wps));
-    (void) mx;
-    (void) ms;
+    if (wps == 8) printf("   | slowest wave %.0f ticks in %.3f ms of wall = %.0f ticks/us", (double) mx, ms, (double) mx / (ms * 1e3));
   }
   printf("\n");
   fflush(stdout);
