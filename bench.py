@@ -4,19 +4,23 @@
 A step = one LSI Query (all query-map segments against the indexed base map: queue clear,
 traversal + predicate kernel, the 48-byte Intersection record of every hit, count read-back, sync
 -- what the reference times, src/run_query.cu:297-303 around src/app/lsi_lbvh.h:27-98)
-followed by one PIP Query (every vertex of the query map, src/run_query.cu:346,441-457).
+and one PIP Query (every vertex of the query map, src/run_query.cu:346,441-457: k_pip_walk, then
+k_pip_exact over the candidate lists it left, then k_pip over the few overflowed ones).
 Workload (N=1): BASELINE.json configs[1], USCounty (base, 7.1 M segments) |><| BlockGroup
 (query, 28.8 M segments), as synthetic stand-ins of those sizes (the real files are
 not obtainable).  Inputs are resident in HBM before the timed region.  Index build is timed
-separately and reported, never part of `value`.
+separately and reported, never part of `value`.  The default single-GPU run also appends
+`secondary` lines (same schema, fewer steps) for the two harder pairs -- USCounty |><|
+NestedBlockGroup (shared vertices, 11x the intersections) and WaterBodies |><| BlockGroup
+(BASELINE config 5's maps) -- so the best-case lattice is never the only number.
 
 N>1 (torchrun, one rank per GPU): the query map is sharded by contiguous chain ranges balanced
-by edge count, the base map + LBVH are replicated.  The one real exchange of a step is the RCCL
-all-gather-v of the intersection queues (every rank needs the pairs that touch ITS edges of either
-map).  PIP results are per-vertex properties of the query map's chains and are consumed by the
-owner of that chain range (the overlay uses them per edge of the same map,
-src/app/map_overlay_lbvh.h:215-236), so by default they stay sharded; --gather-pip adds the
-119 MB all-gather of closest-eid queues to every step.  Total work is fixed: "strong" scaling.
+by edge count, the base map + LBVH are replicated.  The exchanges of a step are the RCCL
+all-gather-v of the intersection queues (count + pairs in one collective on a second stream,
+overlapped with the PIP kernels) and the all-gather of the PIP result queues (closest eids,
+4 bytes per query vertex; it runs while the NEXT step computes, double-buffered, and all of them
+complete inside the timed region).  `ms_per_step_pairs_only` times the same steps without the PIP
+gather.  Total work is fixed: "strong" scaling.
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,13 +36,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+SECONDARY = (("USCounty", "NestedBlockGroup"), ("WaterBodies", "BlockGroup"))
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)    # the reference's -repeat=5
-    ap.add_argument("--warmup", type=int, default=8)   # (the reference: -warmup=5; the first six steps also pick the kernel schedule)
+    ap.add_argument("--warmup", type=int, default=5)   # the reference's -warmup=5 (four pairs settle the kernel schedule)
     ap.add_argument("--base", default="USCounty")
     ap.add_argument("--query", default="BlockGroup")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink both stand-ins (debug only)")
@@ -46,8 +51,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0)
     ap.add_argument("--check", action="store_true", help="size-independent result checks after timing")
-    ap.add_argument("--gather-pip", action="store_true", help="N>1: also all-gather the PIP result queues every step")
-    ap.add_argument("--serial-kernels", action="store_true", help="run the PIP kernel after the LSI kernel instead of beside it")
+    ap.add_argument("--no-gather-pip", action="store_true", help="N>1: leave the PIP result queues with their shards (round-2 behaviour)")
+    ap.add_argument("--gather-pip", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--serial-kernels", action="store_true", help="run the PIP kernels after the LSI kernel instead of beside it")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (nested and WaterBodies pairs)")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="N",
                     help="diagnostic, 1 GPU: time rank 0's shard of an N-way run (no exchange); the line is marked as such")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
@@ -55,18 +62,18 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, ctx):
+def cpu_baseline(args, ctx, base_name, query_name):
     """CPU restatement of -mode=grid (the oracle, kind 'port') timed beside the GPU numbers, on
-    all host cores.  Default sample = the whole workload (about 10-20 s of query work on 16
-    cores); --cpu-scale < 1 regenerates both stand-ins at that fraction of the lattice resolution
+    all host cores.  Default sample = the whole workload (0.1-0.8 s of query work on 64
+    threads); --cpu-scale < 1 regenerates both stand-ins at that fraction of the lattice resolution
     (same per-segment geometry, ~scale^2 of the segments).  Query time only, like the GPU side."""
     from oracle import rjoracle as O
     from rayjoin_amd import maps, synth
     # all host cores this process may use, capped: the GPU box is shared
     O.lib().rjo_set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
     if args.cpu_scale != 1.0:
-        g0 = synth.standin(args.base, args.cpu_scale * args.scale)
-        g1 = synth.standin(args.query, args.cpu_scale * args.scale)
+        g0 = synth.standin(base_name, args.cpu_scale * args.scale)
+        g1 = synth.standin(query_name, args.cpu_scale * args.scale)
         ctx = maps.Context([g0, g1]).load()
     m0 = O.Map(ctx.maps[0].pts, ctx.maps[0].row_index, ctx.maps[0].left, ctx.maps[0].right)
     m1 = O.Map(ctx.maps[1].pts, ctx.maps[1].row_index, ctx.maps[1].left, ctx.maps[1].right)
@@ -93,41 +100,22 @@ def cpu_baseline(args, ctx):
         "cores": O.num_threads(), "kind": "port",
         "sample": "%s x %s stand-ins at %.3g of the lattice resolution (1 = the whole workload): %d base / %d query segments, "
                   "%d intersections; grid_size %d; lsi %.1f ms, pip %.1f ms (grid build %.1f ms not counted)"
-                  % (args.base, args.query, args.cpu_scale * args.scale, m0.ne, m1.ne, n, gsize,
+                  % (base_name, query_name, args.cpu_scale * args.scale, m0.ne, m1.ne, n, gsize,
                      t_lsi * 1e3, t_pip * 1e3, t_build * 1e3),
         "lsi_msegs_per_s": round(m1.ne / t_lsi / 1e6, 4),
         "pip_mpoints_per_s": round(pts.shape[0] / t_pip / 1e6, 4),
     }
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
-    if args.rehearse_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
+def run_workload(args, env, base_name, query_name, steps, warmup, headline, with_cpu):
+    """Times `steps` steps of base |><| query on this rank's shard; rank 0 returns the line (a dict)."""
+    torch, dist, dev, world, rank, local_rank = env
     from rayjoin_amd import _capi, maps, synth
+    from rayjoin_amd import dist as rjd
 
     # ---- synthetic workload (identical on every rank: seeded) -------------------------------
     t0 = time.perf_counter()
-    g0 = synth.standin(args.base, args.scale)
-    g1 = synth.standin(args.query, args.scale)
-    ctx = maps.Context([g0, g1]).load()
+    ctx = maps.Context([synth.standin(base_name, args.scale), synth.standin(query_name, args.scale)]).load()
     base, query = ctx.maps[0], ctx.maps[1]
     t_gen = time.perf_counter() - t0
     n_r, n_s, n_p = base.n_edges, query.n_edges, query.n_points
@@ -141,34 +129,41 @@ def main():
     h.build_lbvh(0)
     h.build_lbvh(0)  # second build = steady-state allocator
     if not args.serial_kernels:
-        # LSI and PIP of a step are independent: "auto" tries them one after the other, sharing the chip and beside
-        # each other on full grids during the first six steps and keeps the fastest schedule (include/rayjoin_amd.h)
+        # LSI and PIP of a step are independent: "auto" measures taking turns / sharing the chip / full grids beside
+        # each other on the first four steps and keeps the fastest schedule (include/rayjoin_amd.h)
         h.set_option("pip_concurrent", 2)
     build_ms = h.last_ms(_capi.RJ_T_BUILD)
 
     # ---- shard the query map by chain range -------------------------------------
-    from rayjoin_amd import dist as rjd
     sh = rjd.shard_of(query, args.emulate_shard, 0) if (args.emulate_shard and world == 1) else rjd.shard_of(query, world, rank)
     (e0, e1), (p0, p1) = sh["eids"], sh["points"]
     cap = int(args.xsect_factor * (n_r + n_s))  # run_query.cu:226-228
-    closest = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
-    faces = torch.empty(max(1, p1 - p0), dtype=torch.int32, device=dev)
+    max_pts = max(1, p1 - p0)
+    if world > 1:
+        max_pts = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
+    gather_pip = world > 1 and not args.no_gather_pip
+    # (two result buffers: a step's PIP queue is gathered while the next step fills the other one)
+    closest2 = [torch.empty(max_pts, dtype=torch.int32, device=dev) for _ in range(2 if gather_pip else 1)]
+    faces = torch.empty(max_pts, dtype=torch.int32, device=dev)
     xsects = torch.empty((cap, 6), dtype=torch.int64, device=dev)  # dev::Intersection<int64_t>, 48 B each
     if world > 1:
-        # count + pairs leave in one all-gather on a second stream, overlapped with the PIP kernel
+        # count + pairs leave in one all-gather on a second stream, overlapped with the PIP kernels
         ex = rjd.PairExchange(cap, dev, slot=max(4096, int(0.02 * cap)))
         pairs = ex.pairs
-        max_pts = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
+        pg = rjd.PointGather(max_pts, dev) if gather_pip else None
     else:
         pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        pg = None
 
-    lsi_ms, pip_ms, pts_ms = [], [], []
-    state = {}
+    lsi_ms, pip_ms, walk_ms, pts_ms = [], [], [], []
+    state = {"k": 0}
 
-    def step(record):
+    def step(record, with_gather=True):
+        closest = closest2[state["k"] % len(closest2)]
+        state["k"] += 1
         # everything is enqueued back to back; the step's single host sync is the count read-back
         h.lsi_query_async(0, 1, e0, e1, cap, pairs)
-        # once the handle has settled on running the two kernels beside each other, the PIP query -- the longer
+        # once the handle has settled on running the two sides beside each other, the PIP query -- the longer
         # side, on the handle's second stream -- is issued right behind the LSI query (8-10 us earlier)
         early = h.get_option("pip_schedule") in (1, 2)
         if early:
@@ -183,40 +178,67 @@ def main():
             n = state["cnt_all"][rank]
         else:
             n = h.lsi_query_finish(cap)
-        h.sync()  # joins the PIP kernel, which runs on the handle's second stream beside the LSI kernel
+        h.sync()  # joins the PIP kernels, which run on the handle's second stream beside the LSI kernel
         if record:
             lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
             pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
             pts_ms.append(h.last_ms(_capi.RJ_T_LSI_POINTS))
-        if world > 1 and args.gather_pip:  # optional: all-gather of the PIP result queues
-            state["ids_all"] = rjd.allgather_point_results(closest, p1 - p0, max_pts)
+            if state["two_pass"]:
+                walk_ms.append(h.last_ms(_capi.RJ_T_PIP_WALK))
+        if pg is not None and with_gather:  # all-gather of this step's PIP result queue, behind the next step's kernels
+            pg.begin(closest)
         state["n"] = n
+        state["closest"] = closest
 
     def barrier():
+        if pg is not None:
+            state["ids_all"] = pg.finish()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def timed(k, with_gather=True):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(True, with_gather)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    state["two_pass"] = h.get_option("pip_walk") != 0
+    # setup, like the second index build above: one synchronous query of each kind, so that the first PAIR -- whose
+    # solo times set the split of the shared schedule -- does not also pay the first touch of every buffer
+    h.lsi_query(0, 1, e0, e1, cap, pairs)
+    h.pip_query(0, 1, None, p0, p1 - p0, closest2[0], faces)
+    for _ in range(warmup):
         step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # the kernel schedule must be settled before anything is timed: four measured pairs do it, i.e. the fifth
+    # warm-up step already runs the chosen schedule; with fewer warm-ups (or --serial-kernels) the line says so
+    settled = args.serial_kernels or h.get_option("pip_schedule") >= 0
+    elapsed = timed(steps)
+    ms_per_step = elapsed * 1e3 / steps
+    lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms)); walk_k = float(np.mean(walk_ms)) if walk_ms else None
+    ms_pairs_only = None
+    if gather_pip:
+        ms_pairs_only = timed(steps, with_gather=False) * 1e3 / steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         tot = torch.tensor([state["n"]], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
+        if dist.get_backend() == "gloo":
+            c = tot.cpu(); dist.all_reduce(c); tot = c
+        else:
+            dist.all_reduce(tot)
         n_x = int(tot.item())
     else:
         n_x = state["n"]
-    ms_per_step = elapsed * 1e3 / args.steps
     schedule = h.get_option("pip_schedule")  # (read now: a later index build starts the decision again)
     share = (h.get_option("lsi_share_blocks"), h.get_option("pip_share_blocks"))
+    pip_rest = h.get_option("pip_rest_aux" if schedule in (1, 2) else "pip_rest") if state["two_pass"] else None
+    closest = state["closest"]
 
     # order-independent digest of the step's results, summed over ranks (untimed): lets a test compare
     # an N-rank run with the single-GPU run of the same workload without shipping the results
@@ -240,23 +262,30 @@ def main():
         names = ("pairs", "points_xy", "pip_hits", "pip_eids", "pip_faces")
         return {k: int(x) for k, x in zip(names, v.tolist())}
     result_digest = digest()
+    gathered_ok = None
+    if gather_pip and state.get("ids_all") is not None:
+        # every rank now holds every shard's queue: this rank's slice of the gathered buffer is its own result
+        gathered_ok = bool(torch.equal(state["ids_all"][rank, :p1 - p0], closest[:p1 - p0]))
 
     # phase split (synchronous calls, wall clock), one extra untimed pass
     t0 = time.perf_counter(); h.lsi_query(0, 1, e0, e1, cap, pairs); t_lsi_wall = time.perf_counter() - t0
     t0 = time.perf_counter(); h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); t_pip_wall = time.perf_counter() - t0
     # each kernel with the chip to itself (synchronous queries), median of three
-    alone = {"lsi": [], "pip": []}
+    alone = {"lsi": [], "pip": [], "walk": []}
     for _ in range(3):
         h.lsi_query(0, 1, e0, e1, cap, pairs); alone["lsi"].append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
         h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); alone["pip"].append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
+        if state["two_pass"]:
+            alone["walk"].append(h.last_ms(_capi.RJ_T_PIP_WALK))
     lsi_alone_ms, pip_alone_ms = float(np.median(alone["lsi"])), float(np.median(alone["pip"]))
+    walk_alone_ms = float(np.median(alone["walk"])) if alone["walk"] else None
 
     checks = None
-    if args.check and rank == 0 and world == 1:
+    if args.check and rank == 0 and world == 1 and headline:
         checks = run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1)
 
+    out = None
     if rank == 0:
-        lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms))
         # ALGORITHMIC bytes: every input element once, every output once
         n_s_loc, n_p_loc = e1 - e0, p1 - p0
         b_lsi = 32 * n_s_loc + 32 * n_r + 8 * state["n"]
@@ -265,56 +294,88 @@ def main():
         # workload and only while it was measured on exactly these kernel sources
         traffic, sq, prof_note = {}, {}, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        headline = world == 1 and args.scale == 1.0 and not args.emulate_shard and (args.base, args.query) == ("USCounty", "BlockGroup")
-        if os.path.exists(tp) and headline:
+        is_headline = headline and world == 1 and args.scale == 1.0 and not args.emulate_shard and (base_name, query_name) == ("USCounty", "BlockGroup")
+        if os.path.exists(tp) and is_headline:
             doc = json.load(open(tp))
             if doc.get("kernel_source_hash") == _capi.kernel_source_hash():
                 traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_* (counter passes: each kernel alone on its full grid)" % doc.get("tag")
             else:
                 prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
+        pip_kernel = "k_pip_walk" if state["two_pass"] else "k_pip"
+        # the PIP query's dominant kernel: its own HIP-event time in the timed steps (the three PIP kernels together: query_ms)
+        pip_dom_ms = walk_k if walk_k else pip_k
         roof = {}
-        for name, b, ms, kern in (("lsi", b_lsi, lsi_k, "k_lsi"), ("pip", b_pip, pip_k, "k_pip")):
+        for name, b, ms, kern in (("lsi", b_lsi, lsi_k, "k_lsi"), ("pip", b_pip, pip_dom_ms, pip_kernel)):
             ach = b / (ms * 1e-3) / 1e9
-            roof[name] = {"bound": "hbm", "kernel": kern, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(kern),
-                          "algorithmic_bytes": b, "kernel_ms": round(ms, 4), "pmc_source": prof_note}
+            # `frac` prices the ALGORITHMIC bytes (every input once, every output once) against HBM peak: an
+            # effective-throughput figure.  `traffic` = bytes the kernel actually moved (PMC), `traffic_frac` =
+            # that over the same time and peak: the real bandwidth fraction.
+            r = {"bound": "hbm", "kernel": kern, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic.get(kern),
+                 "algorithmic_bytes": b, "kernel_ms": round(ms, 4), "pmc_source": prof_note}
             c = sq.get(kern, {})
+            alone_ms = lsi_alone_ms if name == "lsi" else (walk_alone_ms or pip_alone_ms)
+            if traffic.get(kern):
+                # (the counter passes run each kernel alone on its full grid: price the bytes against THAT time)
+                r["traffic_frac"] = round(traffic[kern] / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                if traffic[kern] < b:
+                    r["traffic_note"] = ("moves less than the algorithmic bytes: %s" %
+                                         ("a pre-filter built at upload (4-byte cell codes + the base map's occupancy bitmap) skips "
+                                          "the segments of groups with nothing near them" if name == "lsi" else
+                                          "it reads 16-byte boxes and an 8-byte bucket-table entry per base segment, not the 32-byte segment"))
             if c.get("SQ_ACTIVE_INST_VALU") and c.get("GRBM_GUI_ACTIVE"):
-                # busy quad-cycles of the VALUs over the quad-cycles 1024 SIMDs have while the kernel runs
-                # (GRBM_GUI_ACTIVE sums the 8 XCDs): what actually limits a kernel whose HBM traffic is
-                # already the algorithmic minimum
+                # busy quad-cycles of the VALUs over the quad-cycles 1024 SIMDs have while the kernel runs (GRBM_GUI_ACTIVE
+                # sums the 8 XCDs; a SIMD issues one VALU instruction per 4 cycles: tools/issue_probe.hip): what
+                # actually limits a kernel whose HBM traffic is nowhere near the roofline
                 avail = c["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
-                roof[name]["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] / avail, 3)
+                r["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] / avail, 3)
                 if c.get("SQ_ACTIVE_INST_SCA"):  # (same normalisation: scalar-issue quad-cycles per SIMD's waves)
-                    roof[name]["salu_busy_frac"] = round(c["SQ_ACTIVE_INST_SCA"] / avail, 3)
-                if roof[name]["valu_busy_frac"] > 0.6:
-                    roof[name]["limiter"] = "valu-issue"
+                    r["salu_busy_frac"] = round(c["SQ_ACTIVE_INST_SCA"] / avail, 3)
+                if c.get("SQ_INSTS_VALU"):
+                    units = n_p_loc if name == "pip" else n_s_loc
+                    r["valu_per_query"] = round(c["SQ_INSTS_VALU"] / units, 2)
+                    r["salu_per_query"] = round(c.get("SQ_INSTS_SALU", 0) / units, 2)
+                # the measured limiter: the issue port that is busy most of the time, or the latency of dependent loads
+                r["limiter"] = "valu-issue" if r["valu_busy_frac"] > 0.6 else "dependent-load latency"
+                r["limiter_frac"] = r["valu_busy_frac"]
+            roof[name] = r
+        roof["pip"]["query_ms"] = round(pip_k, 4)  # all PIP kernels of a step, first launch to last end
+        roof["pip"]["frac_query"] = round(b_pip / (pip_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
         if schedule in (1, 2):
-            # the two kernels ran BESIDE each other in the timed steps: a kernel's duration there is not what it
+            # the two sides ran BESIDE each other in the timed steps: a kernel's duration there is not what it
             # needs alone, and the durations add up to more than the step -- say so, and add the solo figures
-            for name, b, alone in (("lsi", b_lsi, lsi_alone_ms), ("pip", b_pip, pip_alone_ms)):
-                roof[name]["concurrent_with"] = "k_pip" if name == "lsi" else "k_lsi"
-                roof[name]["kernel_ms_alone"] = round(alone, 4)
-                roof[name]["frac_alone"] = round(b / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            for name, b, alone_ms in (("lsi", b_lsi, lsi_alone_ms), ("pip", b_pip, walk_alone_ms or pip_alone_ms)):
+                roof[name]["concurrent_with"] = pip_kernel if name == "lsi" else "k_lsi"
+                roof[name]["kernel_ms_alone"] = round(alone_ms, 4)
+                roof[name]["frac_alone"] = round(b / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            roof["pip"]["query_ms_alone"] = round(pip_alone_ms, 4)
         dom = "lsi" if lsi_k >= pip_k else "pip"
         b_step = b_lsi + b_pip + 56 * state["n"]  # + the 48-byte records and the pairs read back for them
+        sharding = "single GPU"
+        if world > 1:
+            sharding = ("query map by chain range x%d, base+LBVH replicated, RCCL all-gather-v of LSI pairs (overlapped with the PIP kernels)%s"
+                        % (world, " and all-gather of the PIP result queues (%d B per rank per step, behind the next step's kernels, "
+                                  "double-buffered; all complete inside the timed region)" % (4 * max_pts) if gather_pip
+                           else "; PIP results stay with their shard (--no-gather-pip)"))
+        elif args.emulate_shard:
+            sharding = "DIAGNOSTIC: rank 0's shard of a %d-way run on one GPU, value is NOT a job throughput" % args.emulate_shard
         out = {
-            "metric": "LSI+PIP query throughput, %s |><| %s" % (args.base, args.query),
+            "metric": "LSI+PIP query throughput, %s |><| %s" % (base_name, query_name),
             "value": round(n_s / (ms_per_step * 1e-3) / 1e6, 3), "unit": "M query segments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "int128+f64", "data": "synthetic",
             "config": {"workload": "%s(base, %d segs) |><| %s(query, %d segs, %d points), -query=lsi then -query=pip, "
-                                   "-mode=lbvh (software LBVH)" % (args.base, n_r, args.query, n_s, n_p),
-                       "sharding": ("query map by chain range x%d, base+LBVH replicated, RCCL all-gather-v of LSI pairs%s"
-                                    % (world, " and PIP eids" if args.gather_pip else "; PIP results stay with their shard"))
-                                   if world > 1 else ("single GPU" if not args.emulate_shard else
-                                                      "DIAGNOSTIC: rank 0's shard of a %d-way run on one GPU, value is NOT a job throughput" % args.emulate_shard),
+                                   "-mode=lbvh (software LBVH)" % (base_name, n_r, query_name, n_s, n_p),
+                       "sharding": sharding,
                        "xsect_factor": args.xsect_factor, "queue_capacity": cap, "scale": args.scale,
-                       # what rj_set_option("pip_concurrent", 2) settled on for this workload (rank 0)
-                       "kernel_schedule": {1: "k_lsi and k_pip share the chip (%d + %d blocks)" % share, 0: "k_lsi, then k_pip",
-                                           2: "k_lsi and k_pip beside each other, each on its full grid",
-                                           -1: "undecided (fewer than 7 paired steps)"}[schedule]},
+                       # what rj_set_option("pip_concurrent", 2) settled on for this workload (rank 0), and whether it had
+                       # done so before the first timed step (no schedule trials inside the timed region)
+                       "kernel_schedule": {1: "k_lsi and the PIP kernels share the chip (%d + %d blocks)" % share, 0: "k_lsi, then the PIP kernels",
+                                           2: "k_lsi and the PIP kernels beside each other, each on its full grid",
+                                           -1: "undecided (fewer than 5 paired steps)"}[schedule],
+                       "schedule_settled_before_timing": bool(settled),
+                       "pip_passes": ("k_pip_walk + k_pip_exact + k_pip over %s overflowed lists" % pip_rest) if state["two_pass"] else "k_pip"},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
             "pip_mpoints_per_s": round(n_p / max(t_pip_wall, 1e-9) / 1e6, 2) if world == 1 else None,
@@ -326,21 +387,63 @@ def main():
             "roofline_step": {"bound": "hbm", "achieved": round(b_step / (ms_per_step * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(b_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_step},
         }
+        if ms_pairs_only is not None:
+            out["ms_per_step_pairs_only"] = round(ms_pairs_only, 4)
+            out["pip_gather_verified"] = gathered_ok
         if checks is not None:
             out["checks"] = checks
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, ctx)
+        if with_cpu:
+            out["cpu_baseline"] = cpu_baseline(args, ctx, base_name, query_name)
+    h.close()
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path is the only compute path (no CPU fallback)")
+    if args.rehearse_one_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    env = (torch, dist, dev, world, rank, local_rank)
+
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    out = run_workload(args, env, args.base, args.query, args.steps, args.warmup, True, with_cpu)
+    # the harder pairs, in the same line: only on the default single-GPU run (each adds a few seconds)
+    default_run = world == 1 and not args.emulate_shard and args.scale == 1.0 and (args.base, args.query) == ("USCounty", "BlockGroup")
+    if default_run and not args.no_secondary:
+        sec = []
+        for b, q in SECONDARY:
+            torch.cuda.empty_cache()
+            line = run_workload(args, env, b, q, max(5, min(args.steps, 10)), max(5, args.warmup), False, with_cpu)
+            sec.append({k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "intersections",
+                                             "build_index_ms", "lsi_points_ms", "roofline", "roofline_other", "roofline_step",
+                                             "cpu_baseline") if k in line})
+        out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    h.close()
 
 
 def run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1):
     """Size-independent properties at full size (no oracle can run here in seconds):
-    role symmetry, shard additivity, sortedness/uniqueness, permutation invariance of PIP."""
-    from rayjoin_amd import _capi
+    role symmetry, shard additivity, sortedness/uniqueness, permutation invariance of PIP,
+    and the two-pass PIP against k_pip alone."""
     res = {}
     h.sort_pairs(pairs, n_x)
     a = pairs[:n_x].to(torch.int64)
@@ -372,6 +475,15 @@ def run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1):
     h.pip_query(0, 1, pts, 0, npts, c1, None)
     h.pip_query(0, 1, pts[perm].contiguous(), 0, npts, c2, None)
     res["pip_permutation_invariance"] = bool(torch.equal(c1[perm], c2) and torch.equal(c1, closest[:npts]))
+    # the three PIP passes against k_pip alone, every vertex of the query map: eids and face ids
+    if h.get_option("pip_walk") != 0:
+        n_p = query.n_points
+        c3 = torch.empty(n_p, dtype=torch.int32, device=dev)
+        f3 = torch.empty(n_p, dtype=torch.int32, device=dev)
+        h.set_option("pip_walk", 0)
+        h.pip_query(0, 1, None, 0, n_p, c3, f3)
+        h.set_option("pip_walk", 1)
+        res["pip_two_pass_equals_single_kernel"] = bool(torch.equal(c3, closest[:n_p]) and torch.equal(f3, faces[:n_p]))
     return res
 
 

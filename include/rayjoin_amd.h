@@ -227,16 +227,19 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
 /* options: "stats" 0/1 (instrumented kernels); "chunk_groups" n (consecutive groups handed to a
  * wave at a time; 0 = automatic, the default: 8 for LSI, 6 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
  * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
+ * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
+ * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
+ * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;
  * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
  * consecutive queries are spatially scattered, e.g. the generated workloads of
  * src/run_query.cu:102-167) / 2 always.   "pip_concurrent" 0 never (default) / 1 always /
  * 2 auto: the caller issues rj_lsi_query_async and rj_pip_query_async in PAIRS (the step of a join:
  * both only read the maps and the index) and the two kernels may run beside each other instead of
- * taking turns: with 1 the LSI kernel runs on 1.25 blocks per compute unit and the PIP kernel, on a
- * second stream owned by the handle, on 5 (with 2 the split follows the measured work of the two sides:
- * up to 2.25 + 4).  That is faster on some workloads and slower on others,
- * so "auto" measures the first four pairs (taking turns / sharing the chip as above / beside each other
- * on full grids / the best of those once more), keeps the fastest from the fifth pair on -- the reference's
+ * taking turns: the LSI kernel runs on a reduced grid (1-4 blocks per compute unit: 128 + 736 r blocks per 256
+ * units, r = the measured ratio of the two sides' solo times; 1.75 per unit before anything is measured) and the
+ * PIP kernels, on a second stream owned by the handle, fill the rest.  That is faster on some workloads and slower on others,
+ * so "auto" measures the first four pairs (taking turns / sharing the chip as above / sharing it with the split
+ * corrected by what that showed / beside each other on full grids), keeps the fastest from the fifth pair on -- the reference's
  * five warm-up queries settle it -- and decides again when the index, a map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
  * rj_lsi_query and a PIP query without an LSI query in flight always use the whole chip.)  The PIP
  * query's inputs must be complete when the call

@@ -75,8 +75,8 @@ struct rj_handle_s {
   // other, each on its own full grid (whichever starts first fills the chip, the other fills its
   // ramp and tail).  Which one wins depends on the workload (headline pair: 1 by 9 %; 24-67 M-segment
   // trees: 0 by 35 % over 1; a 1/8 shard against the 24 M-segment tree: 2), so the first pairs run
-  // 0, 1, 2 and the best of those once more (a schedule's first run pays one-time costs) and the fastest is kept
-  // until the index, the maps or the query size change: settled from the fifth pair on.
+  // 0, 1, 1 (split corrected), 2 and the fastest is kept until the index, the maps or the query size change:
+  // settled from the fifth pair on.
   // The span of a pair = start of its LSI kernel .. end of the last of k_lsi, k_lsi_points, k_pip.
   int co_trials = 0;          // pairs measured so far
   float co_best[3] = {1e30f, 1e30f, 1e30f};  // best span [ms] per schedule
@@ -85,14 +85,24 @@ struct rj_handle_s {
   bool co_measure = false;    // the pair in flight is complete (LSI + PIP): its span can be read
   bool co_points = false;     // ... and k_lsi_points ran between them
   uint64_t co_n = 0;          // query size the decision was made for
-  // how the chip is split when shared: both sides should end together, so k_lsi's share follows the
-  // ratio of the two sides' solo times seen in the "taking turns" trial, (k_lsi + k_lsi_points) / k_pip --
-  // measured optima: ratio 0.41 (headline pair) -> 320 + 1280 blocks, 0.72 (nested pair, WaterBodies) -> 576 + 1024
-  float co_ratio = 0.41f;
+  // how the chip is split when shared: both sides should end together, so k_lsi's share follows the ratio of the
+  // two sides' solo times seen in the "taking turns" trial, r = (k_lsi + k_lsi_points) / (the PIP kernels).  Swept per
+  // pair with tools/share_probe.py (profiles/r03_share_sweep.txt; optimum k_lsi grid at r): Zipcode 0.44 -> 448,
+  // headline 0.46 -> 448-512, nested 0.80 -> 576-704, WaterBodies 0.92 -> 832 blocks of 256 CUs' worth:
+  // 128 + 736 r, within 2 % of the best step on all four.  The PIP side (launched second) fills what is left.
+  float co_ratio = 0.46f;
   int lsi_share_set = 0, pip_share_set = 0;  // "lsi_share_set" / "pip_share_set": fixed grids for schedule 1 (0 = derive them, the default)
-  int lsi_share_blocks() const { if (lsi_share_set) return lsi_share_set; int b = ((int) (780.0f * co_ratio * (float) cus / 256.0f) + 32) / 64 * 64; return b < cus * 3 / 4 ? cus * 3 / 4 : (b > cus * 9 / 4 ? cus * 9 / 4 : b); }
-  int pip_share_blocks() const { return lsi_share_blocks() <= cus * 7 / 4 ? cus * 5 : cus * 4; }
+  int co_L = 0, co_best_L = 0;  // the k_lsi grid of the next shared pair / of the best one measured (0: the formula below)
+  int lsi_share_blocks() const {
+    if (lsi_share_set) return lsi_share_set;
+    if (co_L) return co_L;
+    const int b = ((int) ((128.0f + 736.0f * co_ratio) * (float) cus / 256.0f) + 32) / 64 * 64;
+    return b < cus ? cus : (b > cus * 4 ? cus * 4 : b);
+  }
+  int last_pip_share = 0;  // the PIP side's grid in the last shared pair (what "pip_share_blocks" reports)
+  int pip_share_blocks() const { return pip_share_set ? pip_share_set : cus * 5; }  // (k_pip without the walk; the walk gets its full grid less one block per CU)
   bool aux_pending = false;          // something was enqueued on aux_stream since it was last joined
+  hipEvent_t ev_order = nullptr;     // "taking turns" under "pip_concurrent" 2: the PIP kernels still use aux_stream, behind this event
   hipStream_t stream = nullptr;
   MapState map[2];
   BvhState bvh[2];
@@ -226,7 +236,8 @@ hipError_t join_aux(rj_handle h) {
 // ---- "pip_concurrent" 2: which schedule for this pair? ------------------------------------------
 static void co_reset(rj_handle h) {
   h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0;
-  h->co_ratio = 0.41f;
+  h->co_ratio = 0.46f;
+  h->co_L = h->co_best_L = 0;
 }
 static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
   if (!h->co_measure) return;
@@ -245,10 +256,23 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
       h->co_ratio = (a + pts) / pip;
     }
   }
-  if (span < h->co_best[h->co_mode]) h->co_best[h->co_mode] = span;  // (best of two: a schedule's first run pays one-time costs)
+  if (h->co_mode == 1 && h->co_choice < 0 && !h->lsi_share_set) {
+    // sharing: both sides should end together.  The first split comes from the turns pair's ratio -- the first, cold
+    // pair of a workload -- so the second shared trial corrects it by what the first one showed: the side that ended
+    // later gets more of the chip.
+    const int used = h->lsi_share_blocks();
+    if (span < h->co_best[1]) h->co_best_L = used;
+    const float lsi_side = a > c ? a : c;
+    const float imb = (lsi_side - b) / (span > 0 ? span : 1.0f);
+    int next = ((int) ((float) used * (1.0f + 1.5f * imb)) + 16) / 32 * 32;
+    next = next < h->cus ? h->cus : (next > h->cus * 4 ? h->cus * 4 : next);
+    h->co_L = next;
+  }
+  if (span < h->co_best[h->co_mode]) h->co_best[h->co_mode] = span;
   if (++h->co_trials >= kCoTrials && h->co_choice < 0) {
     h->co_choice = 0;
     for (int m = 1; m < 3; m++) if (h->co_best[m] < h->co_best[h->co_choice]) h->co_choice = m;
+    if (h->co_best_L) h->co_L = h->co_best_L;  // (the split of the best shared pair stays)
   }
 }
 static int co_pick(rj_handle h, uint64_t n) {
@@ -256,13 +280,11 @@ static int co_pick(rj_handle h, uint64_t n) {
   if (h->co_n && (n > h->co_n + h->co_n / 4 || n + n / 4 < h->co_n)) co_reset(h);  // another query size: decide again
   h->co_n = n;
   if (h->co_choice >= 0) return h->co_choice;
-  // Four measured pairs -- turns (it also measures the split for "shared"), shared, full grids, and the best
-  // of those three once more (a schedule's first run pays one-time costs) -- so the fifth pair already runs the
-  // settled schedule: the reference's five warm-up queries (run_query.cu:292-296) are enough.
-  if (h->co_trials < 3) return h->co_trials;
-  int best = 0;
-  for (int m = 1; m < 3; m++) if (h->co_best[m] < h->co_best[best]) best = m;
-  return best;
+  // Four measured pairs -- turns (it also measures the split for "shared" and takes the cold start), shared, shared
+  // again with the split corrected, full grids -- so the fifth pair already runs the settled schedule: the
+  // reference's five warm-up queries (run_query.cu:292-296) are enough.
+  static const int kTrial[kCoTrials] = {0, 1, 1, 2};
+  return kTrial[h->co_trials < kCoTrials ? h->co_trials : kCoTrials - 1];
 }
 
 uint64_t pad64(uint64_t n) { return (n + 63) / 64 * 64; }
@@ -326,6 +348,7 @@ int rj_create(int device_id, rj_handle* out) {
   }
   for (int t = 0; ok && t < kNumTimers; t++)
     ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
   if (!ok) { delete h; return RJ_E_HIP; }
   *out = h;
   return RJ_OK;
@@ -342,6 +365,7 @@ int rj_destroy(rj_handle h) {
   (void) hipHostFree(h->h_rest); (void) hipFree(h->rest[0]); (void) hipFree(h->rest[1]); (void) hipFree(h->todo[0]); (void) hipFree(h->todo[1]); (void) hipFree(h->todo_mask[0]); (void) hipFree(h->todo_mask[1]);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
+  if (h->ev_order) (void) hipEventDestroy(h->ev_order);
   (void) hipFree(h->arena);
   if (h->comm) (void) ncclCommDestroy(h->comm);
   (void) hipFree(h->d_counts);
@@ -391,11 +415,13 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_concurrent")) *value = h->pip_concurrent;
   else if (!strcmp(name, "pip_schedule")) *value = h->pip_concurrent == 2 ? h->co_choice : (h->pip_concurrent == 1 ? 1 : 0);
   else if (!strcmp(name, "pip_schedule_trials")) *value = h->co_trials;
+  else if (!strncmp(name, "pip_schedule_us", 15) && name[15] >= '0' && name[15] <= '2' && !name[16])  // best span seen per schedule, microseconds (-1: not measured)
+    *value = h->co_best[name[15] - '0'] < 1e29f ? (int64_t) (h->co_best[name[15] - '0'] * 1000.0f) : -1;
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
   else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
-  else if (!strcmp(name, "pip_share_blocks")) *value = h->pip_share_blocks();
+  else if (!strcmp(name, "pip_share_blocks")) *value = h->last_pip_share ? h->last_pip_share : h->pip_share_blocks();
   else return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
   return RJ_OK;
 }
@@ -879,7 +905,13 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // of the same step on the main stream (both only read the maps and the tree): with an LSI query in
   // flight on its reduced grid (lsi_launch), on 5 blocks per CU; otherwise on the full grid.  Not
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
-  const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight && h->co_mode != 0));
+  // ("auto", taking turns: still the second stream, behind everything the main stream holds so far -- whatever a
+  //  stream costs the first time it is used then lands in the first, cold pair and not in another schedule's trial)
+  const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight));
+  if (aux && h->pip_concurrent == 2 && h->co_mode == 0) {
+    RJ_HIP(h, hipEventRecord(h->ev_order, h->stream));
+    RJ_HIP(h, hipStreamWaitEvent(h->aux_stream, h->ev_order, 0));
+  }
   const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
   h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !order && !h->stats_on && n > 0;
@@ -910,6 +942,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     const int share = h->pip_share_set ? h->pip_share_set : walk_full - h->cus;
     walk_blocks = share < h->max_blocks ? share : h->max_blocks;
   }
+  if (aux && h->lsi_shared) h->last_pip_share = max_blocks;  // (overwritten below when the walk runs)
   // Two passes unless instrumented: k_pip_walk (integer tests only, 8 waves per SIMD) settles every point whose
   // answer is a single certain hit and lists the others; k_pip, the exact kernel, locates those from scratch
   // right behind it, reading the count on the device.  "auto" drops the first pass for a query size whose
@@ -917,15 +950,31 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   const int si = aux ? 1 : 0;
   // (instrumented: k_pip alone, unless "pip_walk" 2 asks for the walk's own counters)
   bool walk = h->pip_walk != 0 && (!h->stats_on || h->pip_walk == 2) && n > 0 && n < (1ull << 32);
-  if (walk && h->pip_walk == 1 && h->walk_n[si] == n && h->h_rest[si] != ~0ull && h->h_rest[si] * 10 > n * 3) walk = false;
+  // how many points the last two-pass query of this size left to k_pip (either stream: the count belongs to the query)
+  uint64_t seen = ~0ull;
+  for (int k : {si, 1 - si})
+    if (seen == ~0ull && h->walk_n[k] == n && h->h_rest[k] != ~0ull) seen = h->h_rest[k];
+  if (walk && h->pip_walk == 1 && seen != ~0ull && seen * 10 > n * 3) walk = false;
   if (walk && h->rest_cap[si] < n) {
-    RJ_HIP(h, hipStreamSynchronize(st));  // (the lists may still be in use by a query in flight)
-    (void) hipFree(h->rest[si]); (void) hipFree(h->todo[si]); (void) hipFree(h->todo_mask[si]);
-    h->rest[si] = nullptr; h->rest_cap[si] = 0; h->todo[si] = nullptr; h->todo_mask[si] = nullptr;
-    if (int r = dev_alloc(h, &h->rest[si], n)) return r;
-    if (int r = dev_alloc(h, &h->todo[si], n * (uint64_t) pip_walk_list_slots())) return r;
-    if (int r = dev_alloc(h, &h->todo_mask[si], n / 4 + 1)) return r;  // (groups of >= 4 points)
-    h->rest_cap[si] = n;
+    // (both streams' lists at once, the first time a size is seen: a later query on the other stream -- the shared
+    //  schedule's trial pair -- must not pay for an allocation inside its measured span)
+    RJ_HIP(h, hipStreamSynchronize(h->stream));  // (the lists may still be in use by a query in flight)
+    RJ_HIP(h, join_aux(h));
+    for (int k = 0; k < 2; k++) {
+      if (h->rest_cap[k] >= n) continue;
+      (void) hipFree(h->rest[k]); (void) hipFree(h->todo[k]); (void) hipFree(h->todo_mask[k]);
+      h->rest[k] = nullptr; h->rest_cap[k] = 0; h->todo[k] = nullptr; h->todo_mask[k] = nullptr;
+      if (int r = dev_alloc(h, &h->rest[k], n)) return r;
+      if (int r = dev_alloc(h, &h->todo[k], n * (uint64_t) pip_walk_list_slots())) return r;
+      if (int r = dev_alloc(h, &h->todo_mask[k], n / 4 + 1)) return r;  // (groups of >= 4 points)
+      h->rest_cap[k] = n;
+      // first touch now, not inside the first query that uses them (fresh device memory is slow to touch: the
+      // shared schedule's trial pair would look 0.15 ms worse than it is)
+      RJ_HIP(h, hipMemsetAsync(h->todo[k], 0xFF, n * (uint64_t) pip_walk_list_slots() * 4, h->stream));
+      RJ_HIP(h, hipMemsetAsync(h->todo_mask[k], 0, (n / 4 + 1) * 8, h->stream));
+      RJ_HIP(h, hipMemsetAsync(h->rest[k], 0, n * 4, h->stream));
+    }
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
   }
   tic(h, RJ_T_PIP_KERNEL, st);
   if (n && walk) {
@@ -940,6 +989,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
     tic(h, RJ_T_PIP_WALK, st);
     RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
+    if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
     toc(h, RJ_T_PIP_WALK, st);
     h->flip_walk[si] = 1 - wflip;
     RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8));
@@ -949,13 +999,13 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     a.rest_count = h->d_rest + si;  // (k_pip reports the count it found to the host)
     // (the list is appended group by group all over the map: the fewer points it holds, the less a wave's points have
     //  to do with each other -- a handful of overflowed lists are unrelated traversals, one wave each)
-    const uint64_t seen = h->walk_n[si] == n && h->h_rest[si] != ~0ull ? h->h_rest[si] : 8192;
-    a.group_lanes = seen < 8192 ? 1 : (seen * 100 < n ? 4 : (seen * 10 < n ? 8 : 16));
+    const uint64_t left = seen != ~0ull ? seen : 8192;
+    a.group_lanes = left < 8192 ? 1 : (left * 100 < n ? 4 : (left * 10 < n ? 8 : 16));
     a.chunk_groups = 1;
     a.stats = nullptr;
     int rest_blocks = max_blocks;
-    if (h->walk_n[si] == n && h->h_rest[si] != ~0ull) {
-      const uint64_t want = h->h_rest[si] / (a.group_lanes * 4 * 2) + 1;  // about two groups per wave
+    if (seen != ~0ull) {
+      const uint64_t want = seen / (a.group_lanes * 4 * 2) + 1;  // about two groups per wave
       const uint64_t floor_blocks = (uint64_t) h->cus;
       rest_blocks = (int) (want < floor_blocks ? floor_blocks : (want > (uint64_t) max_blocks ? (uint64_t) max_blocks : want));
     }
