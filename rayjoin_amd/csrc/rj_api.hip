@@ -27,10 +27,13 @@ struct MapState {
   uint32_t* ccode = nullptr;  // 4-byte cell code per edge (k_lsi's pre-filter stream)
   uint32_t* left = nullptr;
   uint32_t* right = nullptr;
+  std::vector<uint32_t> h_edge_begin;  // host copy of the first eid of every chain (+ sentinel): "leaf_order" 1 cuts its runs from it
+  std::vector<int64_t> h_chain_ends;   // ... and of every chain's first and last point (x, y, x, y): which chains continue each other
 };
 
 struct BvhState {
   bool built = false;
+  int leaf_order = 0;  // how this index's leaves were formed (0 Hilbert neighbours, 1 chain runs)
   uint64_t n0 = 0, n0p = 0;
   Seg* sseg = nullptr;
   uint32_t* seid = nullptr;
@@ -145,6 +148,7 @@ struct rj_handle_s {
   uint32_t *ord_vin = nullptr, *ord_vout = nullptr;
   void* ord_temp = nullptr;
   size_t ord_temp_bytes = 0;
+  int leaf_order = 1;        // "leaf_order" (default 1, or RJ_LEAF_ORDER): what the NEXT rj_build_lbvh makes a leaf of
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
   int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
@@ -191,6 +195,40 @@ int dev_alloc(rj_handle h, T** p, uint64_t count) {
 void free_map(MapState& m) {
   (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.ccode); (void) hipFree(m.left); (void) hipFree(m.right);
   m = MapState();
+}
+
+// Chain-run leaves (the reference's RT grouping: src/rt/primitive.h:120-260, rt_lsi_custom.cu:31-44):
+// a leaf = a run of consecutive eids that form ONE polyline -- a long chain is cut into ceil(len / 64) near-equal
+// pieces; short chains that follow each other in the file are packed together while they fit AND each starts where
+// the one before ended (a polyline cut at every junction, like the lattice stand-ins' rows).  Chains that merely
+// follow each other in the file are not packed: a leaf of unrelated chains has a box as large as their distance
+// (measured: 5x slower PIP on the WaterBodies stand-in at its row ends, 4 orders of magnitude on the gaussian
+// polygons, whose file order is random).  -> run_begin[nruns + 1]
+std::vector<uint32_t> chain_runs(const std::vector<uint32_t>& edge_begin, const std::vector<int64_t>& ends) {
+  std::vector<uint32_t> rb;
+  const size_t nc = edge_begin.empty() ? 0 : edge_begin.size() - 1;
+  uint32_t open_begin = 0, open_len = 0;  // the pack of short chains being filled
+  size_t open_last = 0;                   // ... and its last chain
+  for (size_t c = 0; c < nc; c++) {
+    const uint32_t b = edge_begin[c], len = edge_begin[c + 1] - b;
+    if (len == 0) continue;
+    const bool continues = open_len && ends[4 * open_last + 2] == ends[4 * c] && ends[4 * open_last + 3] == ends[4 * c + 1];
+    if (open_len && (len > 64 || open_len + len > 64 || !continues)) {
+      rb.push_back(open_begin);
+      open_len = 0;
+    }
+    if (len > 64) {
+      const uint32_t k = (len + 63) / 64;
+      for (uint32_t i = 0; i < k; i++) rb.push_back(b + (uint32_t) ((uint64_t) len * i / k));
+    } else {
+      if (!open_len) open_begin = b;
+      open_len += len;
+      open_last = c;
+    }
+  }
+  if (open_len) rb.push_back(open_begin);
+  rb.push_back(nc ? edge_begin[nc] : 0);
+  return rb;
 }
 
 void free_grid(GridState& g) {
@@ -322,6 +360,7 @@ int rj_create(int device_id, rj_handle* out) {
   rj_handle h = new (std::nothrow) rj_handle_s();
   if (!h) return RJ_E_NOMEM;
   h->device = device_id;
+  if (const char* e = getenv("RJ_LEAF_ORDER")) h->leaf_order = atoi(e) == 0 ? 0 : 1;
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
@@ -418,6 +457,9 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strncmp(name, "pip_schedule_us", 15) && name[15] >= '0' && name[15] <= '2' && !name[16])  // best span seen per schedule, microseconds (-1: not measured)
     *value = h->co_best[name[15] - '0'] < 1e29f ? (int64_t) (h->co_best[name[15] - '0'] * 1000.0f) : -1;
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
+  else if (!strcmp(name, "leaf_order")) *value = h->leaf_order;
+  else if (!strcmp(name, "leaf_order_used0") || !strcmp(name, "leaf_order_used1")) *value = h->bvh[name[15] - '0'].leaf_order;  // what the index of map 0 / 1 was built with
+  else if (!strcmp(name, "leaf_slots0") || !strcmp(name, "leaf_slots1")) *value = (int64_t) h->bvh[name[10] - '0'].n0p;  // slots of the index of map 0 / 1 (64 per leaf, padding included)
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
   else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
@@ -436,6 +478,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "pip_concurrent: 0 never, 1 LSI and PIP queries come in pairs and share the chip, 2 the same if it measures faster");
     h->pip_concurrent = (int) value;
     co_reset(h);
+    return RJ_OK;
+  }
+  if (!strcmp(name, "leaf_order")) {
+    if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
+    h->leaf_order = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "pip_walk")) {
@@ -528,6 +575,13 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (rc || e != hipSuccess) free_map(m);  // no half-uploaded map
   if (rc) return rc;
   RJ_HIP(h, e);
+  m.h_edge_begin = std::move(eb);
+  m.h_chain_ends.resize(4 * nc);
+  for (uint64_t c = 0; c < nc; c++) {
+    const uint64_t f = row_index[c], l = row_index[c + 1] - 1;
+    m.h_chain_ends[4 * c] = xy[2 * f]; m.h_chain_ends[4 * c + 1] = xy[2 * f + 1];
+    m.h_chain_ends[4 * c + 2] = xy[2 * l]; m.h_chain_ends[4 * c + 3] = xy[2 * l + 1];
+  }
   m.present = true;
   return RJ_OK;
 }
@@ -610,12 +664,24 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   RJ_HIP(h, join_aux(h));
   const MapState& m = h->map[base_map_id];
   BvhState& b = h->bvh[base_map_id];
-  const bool reuse = b.sseg && b.n0p == pad64(m.ne ? m.ne : 1);  // rebuild of a same-sized map: keep the buffers
+  // "leaf_order" 1: the leaves are runs of consecutive eids, cut on the host from the chain layout
+  std::vector<uint32_t> runs;
+  if (h->leaf_order == 1 && m.ne) {
+    runs = chain_runs(m.h_edge_begin, m.h_chain_ends);
+    // (a map of short chains that do not continue each other -- polygons of a few edges -- would leave its leaves
+    //  mostly empty: above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
+    if ((runs.size() - 1) * 64 > m.ne * 5 / 2) runs.clear();
+  }
+  const uint64_t nruns = runs.empty() ? 0 : runs.size() - 1;
+  const uint64_t n0p_new = nruns ? nruns * 64 : pad64(m.ne ? m.ne : 1);
+  if (n0p_new >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_build_lbvh: %llu leaf slots do not fit 32-bit slot ids", (unsigned long long) n0p_new);
+  const bool reuse = b.sseg && b.n0p == n0p_new;  // rebuild of a same-sized map: keep the buffers
   if (!reuse) free_bvh(b);
   b.built = false;
+  b.leaf_order = nruns ? 1 : 0;
   tic(h, RJ_T_BUILD);
   b.n0 = m.ne;
-  b.n0p = pad64(m.ne ? m.ne : 1);
+  b.n0p = n0p_new;
   // level sizes: level l has ceil(n_{l-1}/64) nodes; top = first level with <= 64 nodes
   b.nlvl[0] = b.n0;
   b.alloc[0] = b.n0p;
@@ -647,20 +713,27 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     if (int r = ensure_sort_scratch(h, m.ne)) return r;
   MortonKey *k_in = h->ord_kin, *k_out = h->ord_kout;
   uint32_t *v_in = h->ord_vin, *v_out = h->ord_vout;
+  uint32_t* d_runs = nullptr;
+  if (nruns) {
+    if (int r = dev_alloc(h, &d_runs, nruns + 1)) return r;
+  }
   hipError_t e = hipSuccess;
   do {
     tic(h, RJ_T_BUILD_KEYS);
-    if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
+    if (nruns) {
+      if ((e = hipMemcpyAsync(d_runs, runs.data(), 4 * (nruns + 1), hipMemcpyHostToDevice, h->stream)) != hipSuccess) break;
+      if ((e = launch_run_keys(h->stream, m.seg, d_runs, nruns, k_in, v_in)) != hipSuccess) break;
+    } else if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_KEYS);
     tic(h, RJ_T_BUILD_SORT);
     if (m.ne) {
       size_t tb = h->ord_temp_bytes;
-      if ((e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
+      if ((e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, nruns ? nruns : m.ne)) != hipSuccess) break;
     }
     toc(h, RJ_T_BUILD_SORT);
     tic(h, RJ_T_BUILD_LEAVES);
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
-    if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, b.n0p / 64, b.alloc[1],
+    if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, d_runs, b.n0p / 64, b.alloc[1],
                                  b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
@@ -679,6 +752,8 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     toc(h, RJ_T_BUILD);
     e = hipStreamSynchronize(h->stream);
   } while (0);
+  if (e != hipSuccess) (void) hipStreamSynchronize(h->stream);  // (d_runs and the host vector may still be read)
+  (void) hipFree(d_runs);
   RJ_HIP(h, e);
   b.built = true;
   co_reset(h);

@@ -99,6 +99,17 @@ __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uin
   }
 }
 
+// Chain-run leaves: the sort key of a run = the Hilbert key of its middle segment's midpoint
+__global__ __launch_bounds__(256) void k_run_keys(const Seg* __restrict__ seg, const uint32_t* __restrict__ run_begin, uint64_t nruns,
+                                                  MortonKey* __restrict__ keys, uint32_t* __restrict__ vals) {
+  for (uint64_t r = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; r < nruns; r += (uint64_t) gridDim.x * blockDim.x) {
+    const Seg s = seg[(run_begin[r] + run_begin[r + 1]) >> 1];
+    const uint64_t mx = (uint64_t) (((s.x1 + s.x2) >> 1) + kCoordOffset), my = (uint64_t) (((s.y1 + s.y2) >> 1) + kCoordOffset);
+    keys[r] = (MortonKey) hilbert16((uint32_t) (mx >> 31), (uint32_t) (my >> 31));
+    vals[r] = (uint32_t) r;
+  }
+}
+
 // Occupancy bitmap of the indexed map: every cell a segment's quantised box touches is set.
 // Two boxes that overlap share a point, hence a cell, so "no set bit under the query box" proves
 // the query can have no candidate: the LSI kernel drops such lanes before the traversal (most of
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       const uint32_t* __restrict__ edge_chain,
                                                       const uint32_t* __restrict__ left,
                                                       const uint32_t* __restrict__ right, uint64_t ne,
+                                                      const uint32_t* __restrict__ run_begin,
                                                       uint64_t nblocks, uint64_t n_parent_alloc,
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
@@ -208,9 +220,17 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
     uint32_t id = 0xFFFFFFFFu;
     int32_t fc = 0;
-    const bool valid = i < ne;
-    if (valid) {
+    // Hilbert leaves: the block's segments are 64 neighbours of the sorted order.  Chain-run leaves ("leaf_order" 1):
+    // the block is one run of consecutive eids (a piece of a chain, or a few whole short chains), `order` sorts the runs.
+    bool valid = i < ne;
+    if (run_begin) {
+      const uint32_t r = order[blk], rb = run_begin[r];
+      valid = (uint32_t) lane < run_begin[r + 1] - rb;
+      if (valid) id = rb + (uint32_t) lane;
+    } else if (valid) {
       id = __builtin_nontemporal_load(&order[i]);
+    }
+    if (valid) {
       s = seg[id];
       const uint32_t c = edge_chain[id];
       fc = (int32_t) (s.x1 < s.x2 ? right[c] : left[c]);
@@ -249,6 +269,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     // first slot and no prefix-max fetch to know its last.
     {
       const int sh = leaf_bucket_shift((uint32_t) (ux1 - ux0));
+      const int nvalid = __popcll(__ballot(valid));
       uint32_t* hw = reinterpret_cast<uint32_t*>(&hist[wib][0]);
       uint32_t packed[2];
 #pragma unroll
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
         wave_lds_fence();
         // pass 0: by the bucket of x0 (this lane's own segment); pass 1: by the bucket of the prefix max of slot `lane`
         // (padding slots sort last and count in neither: a point never scans them)
-        const bool use = pass == 0 ? valid : (uint64_t) blk * 64 + lane < ne;
+        const bool use = pass == 0 ? valid : lane < nvalid;
         const int32_t v = pass == 0 ? b.x0 : m;
         if (use) atomicAdd(&hw[(uint32_t) (v - ux0) >> sh], 1u);
         wave_lds_fence();
@@ -1501,12 +1522,18 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {
   return hipGetLastError();
 }
 
+hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* run_begin, uint64_t nruns, MortonKey* keys, uint32_t* vals) {
+  if (nruns == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_run_keys, dim3(grid_for(nruns, 256, 8192)), dim3(256), 0, st, seg, run_begin, nruns, keys, vals);
+  return hipGetLastError();
+}
+
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
-                               const uint32_t* left, const uint32_t* right, uint64_t ne, uint64_t nblocks,
+                               const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* run_begin, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
                                int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
+                     left, right, ne, run_begin, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
   return hipGetLastError();
 }
 

@@ -1,0 +1,98 @@
+"""Chain-run leaves vs Hilbert-neighbour leaves (rj_set_option "leaf_order", SURVEY 8f-3: the reference's RT grouping,
+src/rt/primitive.h:120-260): the index is a different tree, every result is the same -- against the oracle, for both
+map roles, on chains longer than a leaf (cut into pieces), short chains that continue each other (packed) and short
+chains that do not (the fall-back to Hilbert leaves)."""
+import numpy as np
+import pytest
+
+from rayjoin_amd import _capi, maps, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _omap(oracle, m):
+    return oracle.Map(m.pts, m.row_index, m.left, m.right)
+
+
+def _cut_chains(pg, piece):
+    """every chain of `pg` cut into chains of <= `piece` edges that follow each other in the file, each starting on
+    the point the one before ended on (what a map digitised junction to junction looks like)"""
+    pts, rows, chains = [], [0], []
+    for c in range(pg.n_chains):
+        a, b = int(pg.row_index[c]), int(pg.row_index[c + 1])
+        P = pg.points[a:b]
+        for s0 in range(0, len(P) - 1, piece):
+            part = P[s0:s0 + piece + 1]
+            pts.append(part)
+            rows.append(rows[-1] + len(part))
+            chains.append((len(chains), rows[-2], rows[-1] - 1, pg.chains[c, 3], pg.chains[c, 4]))
+    return maps.PlanarGraph(np.array(chains, dtype=np.int64), np.array(rows, dtype=np.uint32), np.concatenate(pts))
+
+
+def _run(h, base, q, cap):
+    h.build_lbvh(base)
+    pairs = h.alloc(8 * cap)
+    n = h.lsi_query(base, 1 - base, 0, q.n_edges, cap, pairs)
+    h.sort_pairs(pairs, n)
+    closest = h.alloc(4 * q.n_points)
+    face = h.alloc(4 * q.n_points)
+    h.pip_query(base, 1 - base, None, 0, q.n_points, closest, face)
+    return pairs.to_host(np.uint32, 2 * n).reshape(-1, 2).copy(), closest.to_host(np.uint32).copy(), face.to_host(np.int32).copy()
+
+
+@pytest.mark.parametrize("shape", ["long", "short_rows", "mixed"])
+def test_both_leaf_orders_equal_the_oracle(oracle, shape):
+    if shape == "long":      # 150- and 70-edge chains: pieces of 50 and 35
+        g = [synth.lattice_map(7, 150, 21), synth.lattice_map(16, 70, 22)]
+    elif shape == "short_rows":  # 15- and 7-edge chains that continue each other: packed 4 / 9 to a leaf
+        g = [_cut_chains(synth.lattice_map(7, 150, 23), 15), _cut_chains(synth.lattice_map(14, 70, 24), 7)]
+    else:                    # long chains in one map; short unrelated ones in the other (its index falls back)
+        g = [synth.lattice_map(5, 200, 25), synth.lattice_map(30, 7, 26)]
+    ctx = maps.Context(g).load()
+    m = ctx.maps
+    om = [_omap(oracle, m[0]), _omap(oracle, m[1])]
+    want_pairs = oracle.lsi_grid(om[0], om[1], 256)["eid"]
+    h = _capi.Handle(0)
+    try:
+        for i in (0, 1):
+            h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
+        used = {}
+        for order in (1, 0):
+            h.set_option("leaf_order", order)
+            for base in (0, 1):
+                q = m[1 - base]
+                pairs, closest, face = _run(h, base, q, 8 * len(want_pairs) + 1024)
+                used[(order, base)] = h.get_option("leaf_order_used%d" % base)
+                assert np.array_equal(pairs, want_pairs), (shape, order, base)
+                want_e = oracle.pip_grid(om[base], base, q.pts, 256)
+                assert np.array_equal(closest, want_e), (shape, order, base)
+                assert np.array_equal(face, om[base].face_ids(want_e)), (shape, order, base)
+        assert all(used[(0, b)] == 0 for b in (0, 1))
+        assert used[(1, 0)] == 1  # (the chain-run trees really were built)
+        if shape != "mixed":
+            assert used[(1, 1)] == 1 and 64 <= h.get_option("leaf_slots1") / m[1].n_edges * 64 <= 2.5 * 64
+        else:
+            assert used[(1, 1)] == 0  # (7-edge chains that do not continue each other: Hilbert leaves)
+    finally:
+        h.close()
+
+
+def test_unrelated_short_chains_fall_back_to_hilbert_leaves(oracle):
+    """Polygons of a few edges in random file order (the reference's gaussian workload): a leaf per chain would be
+    mostly padding, a leaf of file neighbours would span the map -- the build keeps the Hilbert leaves."""
+    g = synth.gaussian_polygons(400, 5)
+    ctx = maps.Context([g, synth.lattice_map(8, 20, 27)]).load()
+    m = ctx.maps
+    h = _capi.Handle(0)
+    try:
+        for i in (0, 1):
+            h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
+        h.set_option("leaf_order", 1)
+        h.build_lbvh(0)
+        assert h.get_option("leaf_order_used0") == 0 and h.get_option("leaf_slots0") < m[0].n_edges + 64
+        om = [_omap(oracle, m[0]), _omap(oracle, m[1])]
+        closest = h.alloc(4 * m[1].n_points)
+        h.pip_query(0, 1, None, 0, m[1].n_points, closest, None)
+        assert np.array_equal(closest.to_host(np.uint32), oracle.pip_grid(om[0], 0, m[1].pts, 128))
+    finally:
+        h.close()
