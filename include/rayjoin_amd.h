@@ -183,6 +183,11 @@ int rj_comm_destroy(rj_handle h);
  * set) when the total exceeds out_capacity. */
 int rj_allgather_pairs(rj_handle h, const uint32_t* pairs_dev, uint64_t n_local, uint32_t* out_dev,
                        uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total);
+/* The layout of an all-gather-v, as a pure host function (no GPU, no communicator; what rj_allgather_* compute
+ * between their two collectives): offsets[r] = counts[0] + ... + counts[r-1] (rank r's slice starts there, zero
+ * counts take no room), *total = the sum.  RJ_E_OVERFLOW (offsets and *total still set) when total > capacity,
+ * RJ_E_INVALID for nranks < 1, null arrays or a sum that does not fit 64 bits. */
+int rj_allgatherv_plan(const uint64_t* counts, int nranks, uint64_t capacity, uint64_t* offsets, uint64_t* total);
 /* same for a queue of 32-bit values (closest eids / face ids of a point shard) */
 int rj_allgather_u32(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uint32_t* out_dev,
                      uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total);

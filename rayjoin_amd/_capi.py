@@ -47,6 +47,7 @@ SYMBOLS = {
     "rj_comm_destroy": (_int, [_vp]),
     "rj_allgather_pairs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
     "rj_allgather_u32": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
+    "rj_allgatherv_plan": (_int, [_vp, _int, _u64, _vp, C.POINTER(_u64)]),
     "rj_overlay_edge_xsects": (_int, [_vp, _int, _vp, _u64, _vp]),
     "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
@@ -73,6 +74,15 @@ def kernel_source_hash():
         with open(os.path.join(HERE, "csrc", name), "rb") as f:
             hsh.update(f.read())
     return hsh.hexdigest()[:16]
+
+
+def allgatherv_plan(counts, capacity):
+    """rj_allgatherv_plan: (offsets, total, status) of an all-gather-v of `counts` elements per rank (host only)."""
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    off = np.zeros(max(1, counts.shape[0]), dtype=np.uint64)
+    total = _u64()
+    rc = load().rj_allgatherv_plan(counts.ctypes.data, int(counts.shape[0]), int(capacity), off.ctypes.data, C.byref(total))
+    return off[:counts.shape[0]], int(total.value), rc
 
 
 def scale_points(bb, xy, fused=False):

@@ -1267,6 +1267,18 @@ int rj_comm_destroy(rj_handle h) {
   return RJ_OK;
 }
 
+int rj_allgatherv_plan(const uint64_t* counts, int nranks, uint64_t capacity, uint64_t* offsets, uint64_t* total) {
+  if (!counts || !offsets || !total || nranks < 1) return RJ_E_INVALID;
+  uint64_t sum = 0;
+  for (int r = 0; r < nranks; r++) {
+    offsets[r] = sum;
+    if (counts[r] > UINT64_MAX - sum) return RJ_E_INVALID;
+    sum += counts[r];
+  }
+  *total = sum;
+  return sum > capacity ? RJ_E_OVERFLOW : RJ_OK;
+}
+
 // all-gather-v of n_local elements of `elt_words` 32-bit words each
 static int allgatherv_words(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uint32_t* out_dev,
                             uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total, int elt_words) {
@@ -1282,12 +1294,14 @@ static int allgatherv_words(rj_handle h, const uint32_t* src_dev, uint64_t n_loc
   RJ_HIP(h, hipMemcpyAsync(cnt.data(), h->d_counts, 8 * (size_t) P, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   uint64_t total = 0;
-  std::vector<uint64_t> off(P);
-  for (int r = 0; r < P; r++) { off[r] = total; total += cnt[r]; if (counts_out) counts_out[r] = cnt[r]; }
+  std::vector<uint64_t> off(P), cnt64(cnt.begin(), cnt.end());
+  const int plan = rj_allgatherv_plan(cnt64.data(), P, out_capacity, off.data(), &total);
+  for (int r = 0; r < P && counts_out; r++) counts_out[r] = cnt[r];
   if (n_total) *n_total = total;
-  if (total > out_capacity)
+  if (plan == RJ_E_OVERFLOW)
     return fail(h, RJ_E_OVERFLOW, "all-gather-v: %llu elements in total, capacity %llu", (unsigned long long) total,
                 (unsigned long long) out_capacity);
+  if (plan != RJ_OK) return fail(h, plan, "all-gather-v: bad counts");
   // 2. exact slices: my slice goes to every peer, every peer's slice lands at its offset here
   const size_t w = (size_t) elt_words;
   if (n_local)

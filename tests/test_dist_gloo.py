@@ -67,6 +67,16 @@ def _worker(rank, world, port, out_dir):
     max_n = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
     allids = rjd.allgather_point_results(ids, p1 - p0, max_n)
     assert np.array_equal(allids.numpy().astype(np.uint32), want)
+    # ... and the pipelined form bench.py times (begin after a step, finish a step later, double-buffered):
+    # two "steps" with different contents, each gathered buffer complete when it is read
+    pg = rjd.PointGather(max_n, torch.device("cpu"))
+    for rep in range(3):
+        buf = torch.full((max_n,), -1, dtype=torch.int32)
+        buf[:p1 - p0] = ids + rep
+        pg.begin(buf)
+        got = pg.finish()
+        cat = torch.cat([got[r, :b - a] for r, (a, b) in enumerate(rjd.shard_of(query, world, r)["points"] for r in range(world))])
+        assert np.array_equal((cat - rep).numpy().astype(np.uint32), want), "rank %d rep %d: PointGather" % (rank, rep)
     # shards tile the chain range exactly and are balanced by edge count
     rngs = query.shard_chain_ranges(world)
     assert rngs[0][0] == 0 and rngs[-1][1] == query.n_chains
@@ -85,3 +95,26 @@ def test_shard_and_allgatherv_gloo(tmp_path, world):
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok%d" % r))
+
+
+def test_allgatherv_plan_offsets_for_ragged_and_empty_shards():
+    """The layout rj_allgather_pairs / rj_allgather_u32 compute between their two collectives (counts -> offsets,
+    total, overflow) as a pure host function of the C ABI: RCCL itself cannot run with more than one rank on a
+    one-GPU lease, the arithmetic that places every rank's slice can be checked for any N."""
+    import numpy as np
+    from rayjoin_amd import _capi
+    rng = np.random.default_rng(5)
+    cases = [[0], [7], [0, 0], [5, 0], [0, 9], [3, 4, 5], [0, 0, 0], [1, 0, 2], [2 ** 40, 1, 2 ** 41],
+             [0, 0, 6, 0, 0, 0, 1, 0], [11, 0, 13, 17, 0, 19, 23, 29]]
+    cases += [list(rng.integers(0, 1 << 20, n)) for n in (2, 3, 8) for _ in range(4)]
+    for counts in cases:
+        off, total, rc = _capi.allgatherv_plan(counts, sum(counts))
+        assert rc == _capi.RJ_OK and total == sum(counts)
+        assert list(off) == [sum(counts[:r]) for r in range(len(counts))]
+        # slices tile [0, total) exactly, in rank order, empty ranks take no room
+        assert all(int(off[r]) + counts[r] == (int(off[r + 1]) if r + 1 < len(counts) else total) for r in range(len(counts)))
+        if total:
+            off2, total2, rc2 = _capi.allgatherv_plan(counts, total - 1)
+            assert rc2 == _capi.RJ_E_OVERFLOW and total2 == total and list(off2) == list(off)  # (the true total is still reported)
+    assert _capi.allgatherv_plan([], 10)[2] == _capi.RJ_E_INVALID
+    assert _capi.allgatherv_plan([2 ** 63, 2 ** 63], 2 ** 64 - 1)[2] == _capi.RJ_E_INVALID  # the sum does not fit 64 bits
