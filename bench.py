@@ -179,12 +179,13 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         else:
             n = h.lsi_query_finish(cap)
         h.sync()  # joins the PIP kernels, which run on the handle's second stream beside the LSI kernel
-        if record:
-            lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
-            pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
-            pts_ms.append(h.last_ms(_capi.RJ_T_LSI_POINTS))
+        if record:  # (one call for all stages: this sits between two steps)
+            ms = h.last_ms_all()
+            lsi_ms.append(ms[_capi.RJ_T_LSI_KERNEL])
+            pip_ms.append(ms[_capi.RJ_T_PIP_KERNEL])
+            pts_ms.append(ms[_capi.RJ_T_LSI_POINTS])
             if state["two_pass"]:
-                walk_ms.append(h.last_ms(_capi.RJ_T_PIP_WALK))
+                walk_ms.append(ms[_capi.RJ_T_PIP_WALK])
         if pg is not None and with_gather:  # all-gather of this step's PIP result queue, behind the next step's kernels
             pg.begin(closest)
         state["n"] = n

@@ -228,6 +228,23 @@ int rj_last_ms(rj_handle h, int which, float* ms);
  * [3] = box tests in the leaf loop; [4..9] = summed per-wave cycle stamps of the instrumented
  * build (total, node expansion, leaf loop, dense predicate phase, merge rounds, max wave total).
  * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
+/* ---- a step as one submission ------------------------------------------------------------ */
+/* The asynchronous queries issued between rj_graph_begin and rj_graph_end (rj_lsi_query_async, rj_lsi_points_async,
+ * rj_pip_query_async, rj_lsi_count_to -- on both of the handle's streams) are captured into one hipGraph instead of
+ * being run (one graph per stream: the two sides of a step that share the chip must stay on two streams); rj_graph_launch
+ * replays them: two submissions per step of a join instead of seven launches and eight event records (the reference: run_query.cu:297-303 issues its kernels one by one).  The step must
+ * have run once normally (buffers allocated, coherence estimated, "pip_schedule" settled); arguments, grids and
+ * the schedule are frozen as they were at capture; a captured LSI query's count is copied to the host at the end of
+ * the graph and read with rj_graph_lsi_count (which waits for the stream; RJ_E_OVERFLOW like rj_lsi_query_finish).
+ * rj_last_ms works on a replayed step.  Uploading a map or building an index invalidates nothing by itself: capture
+ * again after it.  Not with the instrumented kernels or re-ordered query sets. */
+int rj_graph_begin(rj_handle h, int id); /* id 0..3: a handle keeps up to four captured steps (e.g. one per result buffer) */
+int rj_graph_end(rj_handle h);
+int rj_graph_launch(rj_handle h, int id);
+int rj_graph_lsi_count(rj_handle h, uint64_t capacity, uint64_t* n_found);
+/* every stage at once: ms[i] = rj_last_ms(h, i) for i < n (at most the number of stages), -1 for a stage that has
+ * not run -- one call instead of one per stage between two steps of a timed loop */
+int rj_last_ms_all(rj_handle h, float* ms, int n);
 int rj_last_stats(rj_handle h, uint64_t stats[16]);
 /* options: "stats" 0/1 (instrumented kernels); "chunk_groups" n (consecutive groups handed to a
  * wave at a time; 0 = automatic, the default: 8 for LSI, 6 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64

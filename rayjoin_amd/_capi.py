@@ -48,6 +48,11 @@ SYMBOLS = {
     "rj_allgather_pairs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
     "rj_allgather_u32": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
     "rj_allgatherv_plan": (_int, [_vp, _int, _u64, _vp, C.POINTER(_u64)]),
+    "rj_last_ms_all": (_int, [_vp, _vp, _int]),
+    "rj_graph_begin": (_int, [_vp, _int]),
+    "rj_graph_end": (_int, [_vp]),
+    "rj_graph_launch": (_int, [_vp, _int]),
+    "rj_graph_lsi_count": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "rj_overlay_edge_xsects": (_int, [_vp, _int, _vp, _u64, _vp]),
     "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
@@ -342,6 +347,29 @@ class Handle:
         ms = C.c_float()
         self._check(self.L.rj_last_ms(self.h, which, C.byref(ms)))
         return ms.value
+
+    def graph_begin(self, gid=0):
+        self._check(self.L.rj_graph_begin(self.h, gid))
+
+    def graph_end(self):
+        self._check(self.L.rj_graph_end(self.h))
+
+    def graph_launch(self, gid=0):
+        self._check(self.L.rj_graph_launch(self.h, gid))
+
+    def graph_lsi_count(self, capacity):
+        n = _u64()
+        rc = self.L.rj_graph_lsi_count(self.h, capacity, C.byref(n))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
+        self._check(rc)
+        return n.value
+
+    def last_ms_all(self):
+        """-> list of the last duration of every stage (RJ_T_* order), -1 where a stage has not run"""
+        buf = (C.c_float * 11)()
+        self._check(self.L.rj_last_ms_all(self.h, buf, 11))
+        return list(buf)
 
     def last_stats(self):
         s = (_u64 * 16)()

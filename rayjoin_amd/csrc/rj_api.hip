@@ -106,6 +106,16 @@ struct rj_handle_s {
   int pip_share_blocks() const { return pip_share_set ? pip_share_set : cus * 5; }  // (k_pip without the walk; the walk gets its full grid less one block per CU)
   bool aux_pending = false;          // something was enqueued on aux_stream since it was last joined
   hipEvent_t ev_order = nullptr;     // "taking turns" under "pip_concurrent" 2: the PIP kernels still use aux_stream, behind this event
+  // rj_graph_begin .. rj_graph_end: the async queries issued in between are captured into ONE hipGraph (both streams),
+  // replayed by rj_graph_launch -- a step of a join as one submission instead of seven launches and eight event records
+  bool capturing = false;
+  bool cap_aux = false;              // the second stream is captured too, into a graph of its own
+  bool cap_lsi = false;              // an LSI query is part of it: its count is copied to the host at the end
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static constexpr int kGraphs = 4;   // captured steps per handle (e.g. one per result buffer of a double-buffered caller)
+  int cap_id = 0;                    // the slot being captured
+  hipGraph_t graph[kGraphs] = {nullptr}, graph_aux[kGraphs] = {nullptr};  // one graph per stream: ROCm runs the branches of ONE
+  hipGraphExec_t graph_exec[kGraphs] = {nullptr}, graph_exec_aux[kGraphs] = {nullptr};  // graph one after the other (measured)
   hipStream_t stream = nullptr;
   MapState map[2];
   BvhState bvh[2];
@@ -387,7 +397,9 @@ int rj_create(int device_id, rj_handle* out) {
   }
   for (int t = 0; ok && t < kNumTimers; t++)
     ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!ok) { delete h; return RJ_E_HIP; }
   *out = h;
   return RJ_OK;
@@ -405,6 +417,14 @@ int rj_destroy(rj_handle h) {
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
   if (h->ev_order) (void) hipEventDestroy(h->ev_order);
+  if (h->ev_fork) (void) hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void) hipEventDestroy(h->ev_join);
+  for (int g = 0; g < rj_handle_s::kGraphs; g++) {
+    if (h->graph_exec[g]) (void) hipGraphExecDestroy(h->graph_exec[g]);
+    if (h->graph[g]) (void) hipGraphDestroy(h->graph[g]);
+    if (h->graph_exec_aux[g]) (void) hipGraphExecDestroy(h->graph_exec_aux[g]);
+    if (h->graph_aux[g]) (void) hipGraphDestroy(h->graph_aux[g]);
+  }
   (void) hipFree(h->arena);
   if (h->comm) (void) ncclCommDestroy(h->comm);
   (void) hipFree(h->d_counts);
@@ -434,6 +454,7 @@ int rj_set_stream(rj_handle h, void* s) {
 
 int rj_sync(rj_handle h) {
   RJ_CHECK_H(h);
+  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_sync: a step is being captured (rj_graph_end first)");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   h->lsi_shared = h->lsi_inflight = false;
@@ -774,6 +795,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
     if (cc && cc->valid && cc->begin == key_begin && cc->n == n) {
       incoherent = cc->incoherent;  // same immutable range as last time: no estimate, no sync
     } else {
+      if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its coherence estimate needs a host round trip)");
       RJ_HIP(h, hipMemsetAsync(h->d_counter + 4, 0, 16, h->stream));
       RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_counter + 4));
       RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_counter + 4, 16, hipMemcpyDeviceToHost, h->stream));
@@ -834,7 +856,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.qbeg = qb; a.qend = qe;
   a.base_is_map0 = base_map_id == 0;
   a.out = pairs_dev; a.cap = capacity;
-  const int flip = h->flip_lsi;
+  const int flip = h->capturing ? 0 : h->flip_lsi;  // (a captured step clears its own counters: rj_graph_begin)
   a.counter = h->d_counter + flip;
   a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi + flip * kSchedBlockWords);
   a.next_counter = h->d_counter + (1 - flip);
@@ -853,7 +875,13 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   // "pip_concurrent" 2 decides per workload (co_pick above).
   int max_blocks = h->max_blocks;
   const bool pairable = async_call && h->pip_concurrent != 0 && !order && !h->stats_on && qe > qb;
-  h->co_mode = pairable ? (h->pip_concurrent == 2 ? co_pick(h, qe - qb) : 1) : 0;
+  if (h->capturing) {
+    if (order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
+    h->co_mode = pairable ? (h->pip_concurrent == 2 ? (h->co_choice >= 0 ? h->co_choice : 0) : 1) : 0;
+    h->cap_lsi = true;
+  } else {
+    h->co_mode = pairable ? (h->pip_concurrent == 2 ? co_pick(h, qe - qb) : 1) : 0;
+  }
   h->lsi_inflight = async_call && qe > qb;
   h->co_measure = h->co_points = false;
   h->lsi_shared = pairable && h->co_mode == 1;
@@ -861,7 +889,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
   if (qe > qb) {
     RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks));
-    h->flip_lsi = 1 - flip;
+    if (!h->capturing) h->flip_lsi = 1 - flip;
   } else {
     RJ_HIP(h, hipMemsetAsync(a.counter, 0, 8, h->stream));  // (an empty query: nothing ran that could have counted)
   }
@@ -878,6 +906,7 @@ int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t 
 
 int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   RJ_CHECK_H(h);
+  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_lsi_query_finish: a step is being captured (its count arrives with rj_graph_lsi_count)");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream));
   if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
@@ -982,18 +1011,20 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
   // ("auto", taking turns: still the second stream, behind everything the main stream holds so far -- whatever a
   //  stream costs the first time it is used then lands in the first, cold pair and not in another schedule's trial)
-  const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight));
-  if (aux && h->pip_concurrent == 2 && h->co_mode == 0) {
+  const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight)) &&
+                   !(h->capturing && !h->cap_aux);  // (a captured step that takes turns is one stream's graph)
+  if (aux && !h->capturing && h->pip_concurrent == 2 && h->co_mode == 0) {
     RJ_HIP(h, hipEventRecord(h->ev_order, h->stream));
     RJ_HIP(h, hipStreamWaitEvent(h->aux_stream, h->ev_order, 0));
   }
+  if (h->capturing && order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
   const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
-  h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !order && !h->stats_on && n > 0;
+  h->co_measure = !h->capturing && h->pip_concurrent == 2 && h->lsi_inflight && !order && !h->stats_on && n > 0;
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
   // in flight together (calls on ONE stream are ordered by the stream)
-  const int pflip = h->flip_pip[aux ? 1 : 0];  // (cleared by the previous launch on this stream, see kSchedLsi)
+  const int pflip = h->capturing ? 0 : h->flip_pip[aux ? 1 : 0];  // (cleared by the previous launch on this stream, see kSchedLsi)
   unsigned long long* sched = h->d_counter + (aux ? kSchedPipAux : kSchedPipMain) + pflip * kSchedBlockWords;
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
@@ -1030,6 +1061,8 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   for (int k : {si, 1 - si})
     if (seen == ~0ull && h->walk_n[k] == n && h->h_rest[k] != ~0ull) seen = h->h_rest[k];
   if (walk && h->pip_walk == 1 && seen != ~0ull && seen * 10 > n * 3) walk = false;
+  if (walk && h->rest_cap[si] < n && h->capturing)
+    return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its buffers are allocated on first use)");
   if (walk && h->rest_cap[si] < n) {
     // (both streams' lists at once, the first time a size is seen: a later query on the other stream -- the shared
     //  schedule's trial pair -- must not pay for an allocation inside its measured span)
@@ -1053,7 +1086,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   }
   tic(h, RJ_T_PIP_KERNEL, st);
   if (n && walk) {
-    const int wflip = h->flip_walk[si];
+    const int wflip = h->capturing ? 0 : h->flip_walk[si];
     PipArgs w = a;
     w.work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + wflip * kSchedBlockWords);
     w.next_work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + (1 - wflip) * kSchedBlockWords);
@@ -1066,7 +1099,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
     if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
     toc(h, RJ_T_PIP_WALK, st);
-    h->flip_walk[si] = 1 - wflip;
+    if (!h->capturing) h->flip_walk[si] = 1 - wflip;
     RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8));
     // second pass over what is left: the grid follows the last count seen for this query size
     a.order = h->rest[si];
@@ -1086,10 +1119,10 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     }
     h->walk_n[si] = n;
     RJ_HIP(h, launch_pip(st, a, false, rest_blocks));
-    h->flip_pip[si] = 1 - pflip;
+    if (!h->capturing) h->flip_pip[si] = 1 - pflip;
   } else if (n) {
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
-    h->flip_pip[aux ? 1 : 0] = 1 - pflip;
+    if (!h->capturing) h->flip_pip[aux ? 1 : 0] = 1 - pflip;
   }
   toc(h, RJ_T_PIP_KERNEL, st);
   if (aux) h->aux_pending = true;
@@ -1400,6 +1433,125 @@ int rj_last_ms(rj_handle h, int which, float* ms) {
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipEventSynchronize(h->ev[which][1]));
   RJ_HIP(h, hipEventElapsedTime(ms, h->ev[which][0], h->ev[which][1]));
+  return RJ_OK;
+}
+
+int rj_graph_begin(rj_handle h, int id) {
+  RJ_CHECK_H(h);
+  if (id < 0 || id >= rj_handle_s::kGraphs) return fail(h, RJ_E_INVALID, "rj_graph_begin: id must be 0..%d", rj_handle_s::kGraphs - 1);
+  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_begin: already capturing");
+  if (h->stats_on) return fail(h, RJ_E_INVALID, "rj_graph_begin: not with the instrumented kernels");
+  if (h->pip_concurrent == 2 && h->co_choice < 0)
+    return fail(h, RJ_E_INVALID, "rj_graph_begin: the kernel schedule is still being measured (\"pip_schedule\" is -1): run more paired steps first");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  RJ_HIP(h, join_aux(h));
+  h->lsi_shared = h->lsi_inflight = false;
+  h->cap_id = id;
+  if (h->graph_exec[id]) { (void) hipGraphExecDestroy(h->graph_exec[id]); h->graph_exec[id] = nullptr; }
+  if (h->graph[id]) { (void) hipGraphDestroy(h->graph[id]); h->graph[id] = nullptr; }
+  if (h->graph_exec_aux[id]) { (void) hipGraphExecDestroy(h->graph_exec_aux[id]); h->graph_exec_aux[id] = nullptr; }
+  if (h->graph_aux[id]) { (void) hipGraphDestroy(h->graph_aux[id]); h->graph_aux[id] = nullptr; }
+  // Beside each other = one graph PER STREAM, replayed on its own stream: the branches of one graph run one after
+  // the other on this ROCm (a fork/join capture of the step took 1.58 ms where the plain launches take 0.95).
+  // Taking turns = the main stream's graph alone.
+  const bool two = h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->co_choice != 0);
+  RJ_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+  hipError_t e = hipSuccess;
+  if (two) e = hipStreamBeginCapture(h->aux_stream, hipStreamCaptureModeRelaxed);
+  h->capturing = true;
+  h->cap_aux = two && e == hipSuccess;
+  h->cap_lsi = false;
+  // a replayed step cannot alternate between two counter sets (its arguments are frozen): it uses set 0 of every kind
+  // and clears them first (the kernels still clear set 1, which nothing reads); each stream clears what its kernels use
+  if (e == hipSuccess) e = hipMemsetAsync(h->d_counter, 0, 16, h->stream);                                // LSI result counts
+  if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kRestCountWord, 0, 16, h->stream);               // the main stream's rest counts
+  for (size_t blk : {kSchedLsi, kSchedPipMain, kSchedWalkMain})
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + blk, 0, 8 * 128, h->stream);                   // 8 counters, 128 B apart
+  if (h->cap_aux) {
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kRestCountWord + 2, 0, 16, h->aux_stream);
+    for (size_t blk : {kSchedPipAux, kSchedWalkAux})
+      if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + blk, 0, 8 * 128, h->aux_stream);
+  }
+  if (e != hipSuccess) {
+    hipGraph_t g = nullptr;
+    (void) hipStreamEndCapture(h->stream, &g);
+    if (g) (void) hipGraphDestroy(g);
+    if (h->cap_aux) { g = nullptr; (void) hipStreamEndCapture(h->aux_stream, &g); if (g) (void) hipGraphDestroy(g); }
+    h->capturing = h->cap_aux = false;
+    RJ_HIP(h, e);
+  }
+  return RJ_OK;
+}
+
+int rj_graph_end(rj_handle h) {
+  RJ_CHECK_H(h);
+  if (!h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_end: rj_graph_begin first");
+  hipError_t e = hipSuccess;
+  // the step's one read-back: the intersection count, into pinned memory (rj_graph_lsi_count reads it after the stream is done)
+  if (h->cap_lsi) e = hipMemcpyAsync(h->h_pinned, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream);
+  hipGraph_t g = nullptr, ga = nullptr;
+  hipError_t ec = hipStreamEndCapture(h->stream, &g);
+  if (h->cap_aux) {
+    const hipError_t ea = hipStreamEndCapture(h->aux_stream, &ga);
+    if (ec == hipSuccess) ec = ea;
+  }
+  h->capturing = false;
+  h->lsi_shared = h->lsi_inflight = false;
+  h->co_measure = false;
+  h->aux_pending = false;
+  if (e == hipSuccess) e = ec;
+  if (e != hipSuccess || !g || (h->cap_aux && !ga)) {
+    if (g) (void) hipGraphDestroy(g);
+    if (ga) (void) hipGraphDestroy(ga);
+    h->cap_aux = false;
+    return fail(h, RJ_E_HIP, "rj_graph_end: capture failed: %s", hipGetErrorString(e));
+  }
+  h->cap_aux = false;
+  h->graph[h->cap_id] = g;
+  h->graph_aux[h->cap_id] = ga;
+  RJ_HIP(h, hipGraphInstantiate(&h->graph_exec[h->cap_id], g, nullptr, nullptr, 0));
+  if (ga) RJ_HIP(h, hipGraphInstantiate(&h->graph_exec_aux[h->cap_id], ga, nullptr, nullptr, 0));
+  return RJ_OK;
+}
+
+int rj_graph_launch(rj_handle h, int id) {
+  RJ_CHECK_H(h);
+  if (id < 0 || id >= rj_handle_s::kGraphs || !h->graph_exec[id] || h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_launch: no captured step %d", id);
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipGraphLaunch(h->graph_exec[id], h->stream));
+  if (h->graph_exec_aux[id]) {
+    RJ_HIP(h, hipGraphLaunch(h->graph_exec_aux[id], h->aux_stream));
+    h->aux_pending = true;  // (rj_sync / rj_graph_lsi_count + rj_sync join it)
+  }
+  return RJ_OK;
+}
+
+int rj_graph_lsi_count(rj_handle h, uint64_t capacity, uint64_t* n_found) {
+  RJ_CHECK_H(h);
+  bool any = false;
+  for (int g = 0; g < rj_handle_s::kGraphs; g++) any = any || h->graph_exec[g];
+  if (!any) return fail(h, RJ_E_INVALID, "rj_graph_lsi_count: no captured step");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  const uint64_t n = h->h_pinned[0];
+  if (n_found) *n_found = n;
+  if (int r = check_fault(h)) return r;
+  if (n > capacity)
+    return fail(h, RJ_E_OVERFLOW, "intersection queue overflow: %llu found, capacity %llu", (unsigned long long) n, (unsigned long long) capacity);
+  return RJ_OK;
+}
+
+int rj_last_ms_all(rj_handle h, float* ms, int n) {
+  RJ_CHECK_H(h);
+  if (!ms || n < 0) return fail(h, RJ_E_INVALID, "rj_last_ms_all: bad arguments");
+  if (int r = set_device(h)) return r;
+  for (int t = 0; t < n; t++) {
+    ms[t] = -1.0f;
+    if (t >= kNumTimers || !h->ev_valid[t]) continue;
+    RJ_HIP(h, hipEventSynchronize(h->ev[t][1]));
+    RJ_HIP(h, hipEventElapsedTime(&ms[t], h->ev[t][0], h->ev[t][1]));
+  }
   return RJ_OK;
 }
 

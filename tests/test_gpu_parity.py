@@ -471,3 +471,60 @@ def test_async_query_leaves_complete_records(oracle, lattice_pair):
     got = recs.to_host(_capi.XSECT_DTYPE, small)
     ref = oracle.lsi_points(m0, m1, np.ascontiguousarray(got["eid"]))
     assert np.array_equal(got["x_num"], ref["x_num"]) and np.array_equal(got["y_num"], ref["y_num"])
+
+
+def test_captured_step_replays_the_same_results(oracle):
+    """rj_graph_begin .. rj_graph_end captures a step (LSI + records + PIP, both streams, one graph per stream) and
+    rj_graph_launch replays it: results of every replay equal the plain launches' and the oracle's, for the schedule
+    that shares the chip and for taking turns; what cannot be captured says so."""
+    ctx = maps.Context([synth.lattice_map(9, 120, 31), synth.lattice_map(21, 50, 32)]).load()
+    b, q = ctx.maps
+    m0, m1 = _omap(oracle, b), _omap(oracle, q)
+    want_pairs = oracle.lsi_grid(m0, m1, 256)["eid"]
+    want_eids = oracle.pip_grid(m0, 0, q.pts, 256)
+    h = _capi.Handle(0)
+    try:
+        h.upload_map(0, b.pts, b.row_index, b.left, b.right)
+        h.upload_map(1, q.pts, q.row_index, q.left, q.right)
+        h.build_lbvh(0)
+        h.set_option("query_order", 0)  # (re-ordered queries are never captured: shared scratch)
+        cap = 4 * len(want_pairs) + 64
+        pairs, xs = h.alloc(8 * cap), h.alloc(48 * cap)
+        closest, faces = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+
+        def enqueue():
+            h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs)
+            h.pip_query(0, 1, None, 0, q.n_points, closest, faces, sync=False)
+            h.lsi_points_async(pairs, cap, xs)
+
+        with pytest.raises(_capi.RayJoinError):  # nothing has run yet: the PIP passes' buffers do not exist
+            h.graph_begin(0)
+            try:
+                enqueue()
+            finally:
+                h.graph_end()
+        enqueue(); h.lsi_query_finish(cap); h.sync()
+        for conc in (1, 0):
+            h.set_option("pip_concurrent", conc)
+            enqueue(); n = h.lsi_query_finish(cap); h.sync()
+            assert n == len(want_pairs)
+            h.graph_begin(conc)
+            enqueue()
+            with pytest.raises(_capi.RayJoinError):
+                h.sync()  # a sync cannot be captured
+            h.graph_end()
+            for rep in range(3):
+                closest.from_host(np.zeros(q.n_points, dtype=np.uint32))
+                h.graph_launch(conc)
+                n = h.graph_lsi_count(cap)
+                h.sync()
+                assert n == len(want_pairs)
+                assert np.array_equal(closest.to_host(np.uint32), want_eids), (conc, rep)
+                assert np.array_equal(faces.to_host(np.int32), m0.face_ids(want_eids))
+                got = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
+                assert np.array_equal(oracle.sort_pairs(got.copy()), want_pairs)
+            assert h.last_ms(_capi.RJ_T_PIP_KERNEL) > 0 and h.last_ms(_capi.RJ_T_LSI_KERNEL) > 0
+        with pytest.raises(_capi.RayJoinError):
+            h.graph_launch(3)  # never captured
+    finally:
+        h.close()

@@ -30,6 +30,19 @@ def short(name):
     return name.split("(")[0][:40]
 
 
+KERNELS = ("k_lsi", "k_pip_walk", "k_pip_exact", "k_pip")
+
+
+def full_grid(vals):
+    """k_pip runs twice per PIP query of a profiled run: never on the whole query map (it only takes the walk's
+    overflowed lists).  Counter values of launches that did next to nothing would halve an average: keep the
+    launches within 4x of the largest."""
+    if not vals:
+        return vals
+    top = max(vals)
+    return [v for v in vals if v * 4 >= top]
+
+
 def collect(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -45,8 +58,8 @@ def main():
             f.write("counter,kernel,dispatches,avg_value\n")
             for d in sys.argv[4:]:
                 for counter, per_kernel in sorted(collect(d).items()):
-                    for kern in ("k_lsi", "k_pip"):
-                        v = per_kernel.get(kern)
+                    for kern in KERNELS:
+                        v = full_grid(per_kernel.get(kern))
                         if v:
                             f.write("%s,%s,%d,%.0f\n" % (counter, kern, len(v), sum(v) / len(v)))
     acc = collect(fetch_dir)
@@ -55,6 +68,7 @@ def main():
     rows = []
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for kern, vals in sorted(acc.get(counter, {}).items()):
+            vals = full_grid(vals) if kern in KERNELS else vals
             rows.append((counter, kern, len(vals), sum(vals) / len(vals)))
     out = os.path.join(ROOT, "profiles", "%s_pmc_summary.csv" % tag)
     with open(out, "w") as f:
@@ -63,15 +77,15 @@ def main():
             f.write("%s,%s,%d,%.1f\n" % r)
     avg = {(c, k): v for c, k, _, v in rows}
     traffic = {}
-    for kern in ("k_lsi", "k_pip"):
+    for kern in KERNELS:
         if ("FETCH_SIZE", kern) in avg and ("WRITE_SIZE", kern) in avg:
             traffic[kern] = int((2 * avg[("FETCH_SIZE", kern)] + avg[("WRITE_SIZE", kern)]) * 1024)
     # instruction-issue evidence for the bench line's "limiter" (SQ passes, optional)
     sq = {}
     for d in sys.argv[4:]:
         for counter, per_kernel in collect(d).items():
-            for kern in ("k_lsi", "k_pip"):
-                v = per_kernel.get(kern)
+            for kern in KERNELS:
+                v = full_grid(per_kernel.get(kern))
                 if v:
                     sq.setdefault(kern, {})[counter] = sum(v) / len(v)
     sys.path.insert(0, ROOT)

@@ -12,12 +12,15 @@ set -e -o pipefail
 TAG=${1:?tag}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-# (40 timed steps: the first six steps of a run try the three kernel schedules, the average should be about the chosen one)
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o g -- python3 $R/bench.py --no-cpu-baseline --steps 40 > $R/gpurun_out/${TAG}_kt.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels > $R/gpurun_out/${TAG}_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels > $R/gpurun_out/${TAG}_write.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq1 -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq1.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq2 -o g -- python3 $R/bench.py --no-cpu-baseline --serial-kernels --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq2.log 2>&1
+# (the driver's flags; the four schedule trials are warm-up steps, every timed step runs the settled schedule;
+#  tools/trace_tables.py splits the per-kernel averages by grid size = by regime)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_kt.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --serial-kernels > $R/gpurun_out/${TAG}_fetch.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --serial-kernels > $R/gpurun_out/${TAG}_write.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq1 -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --serial-kernels --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq1.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_sq2 -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --serial-kernels --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_sq2.log 2>&1
 cd $R
-timeout -k 10 500 python3 bench.py --check 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench.json
+python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --regimes > gpurun_out/${TAG}_kernel_regimes.csv
+python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --steps 3 --skip 4 > gpurun_out/${TAG}_step_trace.txt
+timeout -k 10 500 python3 bench.py --check --steps 20 --warmup 5 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench.json
 tail -c 300 gpurun_out/${TAG}_bench.json
