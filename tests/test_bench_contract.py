@@ -21,6 +21,10 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # round 3: the dominant kernel is the PIP walk; the line says what the number is (algorithmic bytes vs moved bytes)
+    assert r["kernel"] in ("k_pip_walk", "k_lsi") and "query_ms" in (r if r["kernel"] == "k_pip_walk" else d["roofline_other"])
+    if r.get("traffic"):
+        assert 0 < r["traffic_frac"] < 1 and r["limiter"] in ("valu-issue", "dependent-load latency") and 0 < r["limiter_frac"] <= 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -29,15 +33,28 @@ def test_committed_bench_line_has_the_contract_fields():
     # value is whole-step throughput of the query map's segments
     n_s = 28793160
     assert abs(d["value"] - n_s / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
+    # the harder pairs ride in the same line, each with its own roofline and CPU baseline
+    assert [s["metric"].split(", ")[1] for s in d["secondary"]] == ["USCounty |><| NestedBlockGroup", "WaterBodies |><| BlockGroup"]
+    for s in d["secondary"]:
+        assert s["value"] > 0 and "roofline" in s and "cpu_baseline" in s and s["config"]["schedule_settled_before_timing"] is True
+
+
+def test_no_schedule_trials_inside_the_timed_region():
+    """Under the driver's flags (--steps 20 --warmup 5) the kernel schedule must be settled before the first timed
+    step: the committed line of exactly that command says so, and this fails if it ever does not."""
+    d = json.load(open(_latest_bench()))
+    assert d["steps"] == 20 and d["warmup"] == 5
+    assert d["config"]["schedule_settled_before_timing"] is True
+    assert "undecided" not in d["config"]["kernel_schedule"]
 
 
 def test_traffic_file_matches_the_kernels_bench_reports():
     """profiles/traffic.json carries the PMC evidence bench.py quotes AND the hash of the kernel
     sources it was measured on; bench.py ignores it when that hash is not the tree's."""
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert set(t["traffic"]) == {"k_lsi", "k_pip"} and all(v > 0 for v in t["traffic"].values())
+    assert {"k_lsi", "k_pip_walk", "k_pip_exact"} <= set(t["traffic"]) and all(v > 0 for v in t["traffic"].values())
     assert len(t["kernel_source_hash"]) == 16 and t["tag"].startswith("r")
-    for k in ("k_lsi", "k_pip"):
+    for k in ("k_lsi", "k_pip_walk"):
         assert t["sq"][k]["SQ_ACTIVE_INST_VALU"] > 0 and t["sq"][k]["GRBM_GUI_ACTIVE"] > 0
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "kernel_source_hash" in src and "stale" in src
