@@ -1060,7 +1060,10 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   uint64_t seen = ~0ull;
   for (int k : {si, 1 - si})
     if (seen == ~0ull && h->walk_n[k] == n && h->h_rest[k] != ~0ull) seen = h->h_rest[k];
-  if (walk && h->pip_walk == 1 && seen != ~0ull && seen * 10 > n * 3) walk = false;
+  // "auto" drops the first pass where it does not pay: most points left over, or many overflowed lists in absolute
+  // terms -- k_pip locates those one scattered handful per wave (the list is in no useful order), which on the gaussian
+  // polygons (25 k of 8 M) costs more than the walk saves
+  if (walk && h->pip_walk == 1 && seen != ~0ull && (seen * 10 > n * 3 || seen > 16384)) walk = false;
   if (walk && h->rest_cap[si] < n && h->capturing)
     return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its buffers are allocated on first use)");
   if (walk && h->rest_cap[si] < n) {

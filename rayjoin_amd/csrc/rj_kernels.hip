@@ -1396,7 +1396,10 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 // queue (__ballot / mbcnt, like k_lsi's pair buffer) and evaluates 64 of them at a time, one point per lane: on a
 // map pair with shared vertices a quarter of the points arrive here, on the headline pair 0.3 %, and either way
 // the lanes that do the 128-bit arithmetic are all busy.
-__global__ __launch_bounds__(256) void k_pip_exact(PipArgs A) {
+#ifndef RJ_EXACT_WAVES
+#define RJ_EXACT_WAVES 5
+#endif
+__global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A) {
   __shared__ uint32_t queue[4][128];
   const DeviceBvh& T = A.bvh;
   const int lane = lane_id();
@@ -1405,28 +1408,52 @@ __global__ __launch_bounds__(256) void k_pip_exact(PipArgs A) {
   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
   auto evaluate = [&](uint32_t i) {
-    // everything a point needs is requested before anything is used: the record's slots, then the segments behind
-    // them (a point's evaluation is otherwise a chain of dependent gathers, and this kernel has little else to hide them)
     const uint64_t ip = A.order ? A.order[i] : i;
     uint32_t slot[kWalkList];
 #pragma unroll
-    for (int r = 0; r < kWalkList; r++) slot[r] = A.todo[(uint64_t) i * kWalkList + r];
+    for (int r = 0; r < kWalkList; r++) slot[r] = A.todo[(uint64_t) i * kWalkList + r];  // (one round trip for the record)
     const int64_t px = A.pts[2 * ip], py = A.pts[2 * ip + 1];
-    Seg seg[kWalkList];
-#pragma unroll
-    for (int r = 0; r < kWalkList; r++) seg[r] = T.sseg[slot[r] != 0xFFFFFFFFu ? slot[r] : 0u];
     double best_yy = __builtin_inf();
     uint32_t best_slot = 0xFFFFFFFFu;
-    Seg best_seg = seg[0];
+    Seg best_seg = {0, 0, 0, 0};
+    // The candidates one after the other, the next one's segment requested while this one is evaluated: a handful of
+    // live registers (the kernel is bound by the latency of these gathers, so resident waves count: 8 per SIMD, where
+    // holding all six segments at once allowed 4), and integer triage before the 128-bit arithmetic --
+    // xsect_y is the double image of a value inside the edge's exact y-range [ylo, yhi], off by less than 2^-6 (two
+    // roundings of a value below 2^46), so an edge with yhi <= py - 1 passes below the point (rejected, diff_y > 0) and
+    // one with ylo >= py + 1 above it (a hit, no substitution); such a sure hit only needs the arithmetic when its
+    // y-range overlaps the best so far.
+    int64_t best_lo = INT64_MAX, best_hi = INT64_MAX;  // exact y-range of the best edge (its xsect_y lies inside, to 2^-6)
+    bool best_exact = false;                           // best_yy has been computed
+    Seg cur = {0, 0, 0, 0};
+    if (slot[0] != 0xFFFFFFFFu) cur = T.sseg[slot[0]];
 #pragma unroll
     for (int r = 0; r < kWalkList; r++) {
+      if (slot[r] == 0xFFFFFFFFu) break;
+      const Seg e = cur;
+      if (r + 1 < kWalkList && slot[r + 1] != 0xFFFFFFFFu) cur = T.sseg[slot[r + 1]];
+      const int64_t x_min = e.x1 < e.x2 ? e.x1 : e.x2, x_max = e.x1 < e.x2 ? e.x2 : e.x1;
+      if (px < x_min || px > x_max || px == (A.query_map_id == 0 ? x_min : x_max)) continue;  // pip.h:44-46, in integers
+      const int64_t ylo = e.y1 < e.y2 ? e.y1 : e.y2, yhi = e.y1 < e.y2 ? e.y2 : e.y1;
+      if (yhi <= py - 1) continue;              // passes below the point
+      if (ylo >= py + 1 && ylo > best_hi) continue;  // a sure hit, but certainly higher than the best so far
+      if (ylo >= py + 1 && yhi < best_lo) {     // a sure hit certainly lower than the best so far: no arithmetic yet
+        best_slot = slot[r]; best_seg = e; best_lo = ylo; best_hi = yhi; best_exact = false;
+        continue;
+      }
+      // overlapping y-ranges, or an edge that touches the point's y: the exact predicate decides
+      if (best_slot != 0xFFFFFFFFu && !best_exact) {
+        double byy;
+        (void) pip_eval_y(best_seg, px, py, A.query_map_id, &byy);  // (a sure hit: always accepted)
+        best_yy = byy; best_exact = true;
+      }
       double yy;
-      if (slot[r] != 0xFFFFFFFFu && pip_eval_y(seg[r], px, py, A.query_map_id, &yy)) {
+      if (pip_eval_y(e, px, py, A.query_map_id, &yy)) {
         bool better = yy < best_yy;
         if (yy == best_yy && best_slot != 0xFFFFFFFFu)  // tie: slope rule, then eid
-          better = pip_better(yy, pip_slope(seg[r]), T.seid[slot[r]], best_yy, pip_slope(best_seg), T.seid[best_slot], A.query_map_id);
+          better = pip_better(yy, pip_slope(e), T.seid[slot[r]], best_yy, pip_slope(best_seg), T.seid[best_slot], A.query_map_id);
         if (better) {
-          best_yy = yy; best_slot = slot[r]; best_seg = seg[r];
+          best_yy = yy; best_slot = slot[r]; best_seg = e; best_lo = ylo; best_hi = yhi; best_exact = true;
         }
       }
     }
