@@ -220,10 +220,14 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         step(False)
     # the kernel schedule must be settled before anything is timed: four measured pairs do it, i.e. the fifth
     # warm-up step already runs the chosen schedule; with fewer warm-ups (or --serial-kernels) the line says so
-    settled = args.serial_kernels or h.get_option("pip_schedule") >= 0
+    # (a re-ordered -- spatially shuffled -- query set is never paired: nothing to settle, one kernel after the other)
+    never_paired = not args.serial_kernels and h.get_option("pip_schedule_trials") == 0 and h.get_option("pip_schedule") < 0
+    settled = args.serial_kernels or never_paired or h.get_option("pip_schedule") >= 0
     elapsed = timed(steps)
     ms_per_step = elapsed * 1e3 / steps
-    lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms)); walk_k = float(np.mean(walk_ms)) if walk_ms else None
+    # ("auto" may have dropped the first PIP pass for this workload: then k_pip is the PIP query)
+    state["two_pass"] = state["two_pass"] and h.get_option("pip_last_passes") == 3
+    lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms)); walk_k = float(np.mean(walk_ms)) if (walk_ms and state["two_pass"]) else None
     ms_pairs_only = None
     if gather_pip:
         ms_pairs_only = timed(steps, with_gather=False) * 1e3 / steps
@@ -238,7 +242,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         n_x = state["n"]
     schedule = h.get_option("pip_schedule")  # (read now: a later index build starts the decision again)
     share = (h.get_option("lsi_share_blocks"), h.get_option("pip_share_blocks"))
-    pip_rest = h.get_option("pip_rest_aux" if schedule in (1, 2) else "pip_rest") if state["two_pass"] else None
+    pip_rest = h.get_option("pip_rest_aux" if schedule in (1, 2) else "pip_rest") if h.get_option("pip_walk") else None
     closest = state["closest"]
 
     # order-independent digest of the step's results, summed over ranks (untimed): lets a test compare
@@ -374,9 +378,11 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                        # done so before the first timed step (no schedule trials inside the timed region)
                        "kernel_schedule": {1: "k_lsi and the PIP kernels share the chip (%d + %d blocks)" % share, 0: "k_lsi, then the PIP kernels",
                                            2: "k_lsi and the PIP kernels beside each other, each on its full grid",
-                                           -1: "undecided (fewer than 5 paired steps)"}[schedule],
+                                           -1: "k_lsi, then the PIP kernels (re-ordered query sets are never paired)" if never_paired
+                                               else "undecided (fewer than 5 paired steps)"}[schedule],
                        "schedule_settled_before_timing": bool(settled),
-                       "pip_passes": ("k_pip_walk + k_pip_exact + k_pip over %s overflowed lists" % pip_rest) if state["two_pass"] else "k_pip"},
+                       "pip_passes": ("k_pip_walk + k_pip_exact + k_pip over %s overflowed lists" % pip_rest) if state["two_pass"]
+                                     else "k_pip alone" + (" (the walk left %s lists to it: auto dropped the first pass)" % pip_rest if h.get_option("pip_walk") else "")},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
             "pip_mpoints_per_s": round(n_p / max(t_pip_wall, 1e-9) / 1e6, 2) if world == 1 else None,

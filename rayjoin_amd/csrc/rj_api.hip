@@ -28,7 +28,7 @@ struct MapState {
   uint32_t* left = nullptr;
   uint32_t* right = nullptr;
   std::vector<uint32_t> h_edge_begin;  // host copy of the first eid of every chain (+ sentinel): "leaf_order" 1 cuts its runs from it
-  std::vector<int64_t> h_chain_ends;   // ... and of every chain's first and last point (x, y, x, y): which chains continue each other
+  std::vector<uint32_t> h_runs;        // chain_runs() of this map, cut once at upload (part of the load phase, like the segment build)
 };
 
 struct BvhState {
@@ -125,6 +125,7 @@ struct rj_handle_s {
   int flip_lsi = 0, flip_pip[2] = {0, 0};  // which of the two counter sets the next launch uses (LSI; PIP on main / aux stream)
   // PIP in two passes (rj_kernels.hip, k_pip_walk): the integer-only walk settles what it can, k_pip takes the rest
   int pip_walk = 1;                        // "pip_walk": 1 auto (default), 0 k_pip alone, 2 always both passes
+  int last_passes = 0;                     // kernels of the last PIP query (3 or 1)
   int flip_walk[2] = {0, 0};
   uint32_t* rest[2] = {nullptr, nullptr};  // per stream (main / aux): points the walk left to k_pip (grow-only)
   uint64_t rest_cap[2] = {0, 0};
@@ -478,6 +479,7 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strncmp(name, "pip_schedule_us", 15) && name[15] >= '0' && name[15] <= '2' && !name[16])  // best span seen per schedule, microseconds (-1: not measured)
     *value = h->co_best[name[15] - '0'] < 1e29f ? (int64_t) (h->co_best[name[15] - '0'] * 1000.0f) : -1;
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
+  else if (!strcmp(name, "pip_last_passes")) *value = h->last_passes;  // how the last PIP query ran: 3 = walk + exact + k_pip, 1 = k_pip alone
   else if (!strcmp(name, "leaf_order")) *value = h->leaf_order;
   else if (!strcmp(name, "leaf_order_used0") || !strcmp(name, "leaf_order_used1")) *value = h->bvh[name[15] - '0'].leaf_order;  // what the index of map 0 / 1 was built with
   else if (!strcmp(name, "leaf_slots0") || !strcmp(name, "leaf_slots1")) *value = (int64_t) h->bvh[name[10] - '0'].n0p;  // slots of the index of map 0 / 1 (64 per leaf, padding included)
@@ -596,13 +598,16 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (rc || e != hipSuccess) free_map(m);  // no half-uploaded map
   if (rc) return rc;
   RJ_HIP(h, e);
-  m.h_edge_begin = std::move(eb);
-  m.h_chain_ends.resize(4 * nc);
-  for (uint64_t c = 0; c < nc; c++) {
-    const uint64_t f = row_index[c], l = row_index[c + 1] - 1;
-    m.h_chain_ends[4 * c] = xy[2 * f]; m.h_chain_ends[4 * c + 1] = xy[2 * f + 1];
-    m.h_chain_ends[4 * c + 2] = xy[2 * l]; m.h_chain_ends[4 * c + 3] = xy[2 * l + 1];
+  {  // the runs "leaf_order" 1 makes leaves of (which chains continue each other is read off the host arrays here)
+    std::vector<int64_t> ends(4 * nc);
+    for (uint64_t c = 0; c < nc; c++) {
+      const uint64_t f = row_index[c], l = row_index[c + 1] - 1;
+      ends[4 * c] = xy[2 * f]; ends[4 * c + 1] = xy[2 * f + 1];
+      ends[4 * c + 2] = xy[2 * l]; ends[4 * c + 3] = xy[2 * l + 1];
+    }
+    m.h_runs = chain_runs(eb, ends);
   }
+  m.h_edge_begin = std::move(eb);
   m.present = true;
   return RJ_OK;
 }
@@ -686,13 +691,10 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   const MapState& m = h->map[base_map_id];
   BvhState& b = h->bvh[base_map_id];
   // "leaf_order" 1: the leaves are runs of consecutive eids, cut on the host from the chain layout
-  std::vector<uint32_t> runs;
-  if (h->leaf_order == 1 && m.ne) {
-    runs = chain_runs(m.h_edge_begin, m.h_chain_ends);
-    // (a map of short chains that do not continue each other -- polygons of a few edges -- would leave its leaves
-    //  mostly empty: above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
-    if ((runs.size() - 1) * 64 > m.ne * 5 / 2) runs.clear();
-  }
+  // (a map of short chains that do not continue each other -- polygons of a few edges -- would leave its leaves
+  //  mostly empty: above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
+  static const std::vector<uint32_t> no_runs;
+  const std::vector<uint32_t>& runs = (h->leaf_order == 1 && m.ne && !m.h_runs.empty() && (m.h_runs.size() - 1) * 64 <= m.ne * 5 / 2) ? m.h_runs : no_runs;
   const uint64_t nruns = runs.empty() ? 0 : runs.size() - 1;
   const uint64_t n0p_new = nruns ? nruns * 64 : pad64(m.ne ? m.ne : 1);
   if (n0p_new >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_build_lbvh: %llu leaf slots do not fit 32-bit slot ids", (unsigned long long) n0p_new);
@@ -1087,6 +1089,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     }
     RJ_HIP(h, hipStreamSynchronize(h->stream));
   }
+  h->last_passes = walk ? 3 : 1;
   tic(h, RJ_T_PIP_KERNEL, st);
   if (n && walk) {
     const int wflip = h->capturing ? 0 : h->flip_walk[si];

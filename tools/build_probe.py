@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rayjoin_amd import _capi, maps, synth  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--maps", default="USCounty,BlockGroup,LakesNA")
+ap.add_argument("--maps", default="USCounty,BlockGroup,WaterBodies,LakesNA")
 ap.add_argument("--scale", type=float, default=1.0)
 ap.add_argument("--reps", type=int, default=5)
 a = ap.parse_args()
@@ -20,11 +20,18 @@ for name in a.maps.split(","):
     m = ctx.maps[0]
     h = _capi.Handle(0)
     h.upload_map(0, m.pts, m.row_index, m.left, m.right)
-    ms = []
-    for _ in range(a.reps):
-        h.build_lbvh(0)
-        ms.append(h.last_ms(_capi.RJ_T_BUILD))
-    out[name] = {"segments": int(m.n_edges), "first_build_ms": round(ms[0], 3), "build_ms": round(min(ms), 3),
-                 "Msegs_per_s": round(m.n_edges / min(ms) / 1e3, 1)}
+    import time
+    out[name] = {"segments": int(m.n_edges)}
+    for order in (1, 0):  # chain-run leaves (the default; the runs are cut on the host: see wall_ms) and Hilbert leaves
+        h.set_option("leaf_order", order)
+        ms, wall = [], []
+        for _ in range(a.reps):
+            t0 = time.perf_counter()
+            h.build_lbvh(0)
+            wall.append((time.perf_counter() - t0) * 1e3)
+            ms.append(h.last_ms(_capi.RJ_T_BUILD))
+        out[name]["leaf_order_%d" % order] = {"used": h.get_option("leaf_order_used0"), "first_build_ms": round(ms[0], 3), "build_ms": round(min(ms), 3),
+                                              "wall_ms": round(min(wall), 3), "Msegs_per_s_device": round(m.n_edges / min(ms) / 1e3, 1),
+                                              "slots_per_segment": round(h.get_option("leaf_slots0") / m.n_edges, 3)}
     h.close()
 print(json.dumps(out))
