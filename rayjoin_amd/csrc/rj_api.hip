@@ -256,7 +256,10 @@ void free_bvh(BvhState& b) {
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
   d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.occ = b.occ;
-  for (int l = 0; l < kMaxLevels; l++) { d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l]; }
+  for (int l = 0; l < kMaxLevels; l++) {
+    d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l];
+    d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
+  }
   d.top = b.top; d.n0 = b.n0;
   return d;
 }

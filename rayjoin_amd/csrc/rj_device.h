@@ -85,6 +85,7 @@ struct DeviceBvh {
   // Behind the boxes of every level l (at lvl[l] + pad64(nlvl[l])) sits one 64-bit word per node:
   // bit k set = sibling k (same 64-entry group) lies HIGHER (box centre, ties by index) -- the
   // precomputed front-to-back order of an upward ray's traversal; see sibling_order().
+  const uint64_t* ord[kMaxLevels];  // where that word array of level l starts
   uint32_t nlvl[kMaxLevels];    // real node count per level
   int top;                // top level: nlvl[top] <= 64
   uint64_t n0;            // real segment count
@@ -98,7 +99,7 @@ __host__ __device__ __forceinline__ int leaf_bucket_shift(uint32_t extent_minus_
   return 24 - __builtin_clz(extent_minus_1);  // (extent_minus_1 >> shift) < 256
 }
 __device__ __forceinline__ const uint64_t* sibling_order(const DeviceBvh& T, int l) {
-  return reinterpret_cast<const uint64_t*>(T.lvl[l] + (((uint64_t) T.nlvl[l] + 63) & ~(uint64_t) 63));
+  return T.ord[l];  // (= lvl[l] + pad64(nlvl[l]): one scalar load instead of a dozen scalar instructions per node expansion)
 }
 __device__ __forceinline__ int lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0));
@@ -113,38 +114,46 @@ __device__ __forceinline__ int32_t quant(int64_t v) { return (int32_t) ((v + kCo
 // then row_bcast:15 / row_bcast:31 fold the four 16-lane rows; the total lands in lane 63 and is
 // returned wave-uniform.  min/max are idempotent, so lanes outside a row_mask keeping their own
 // value is harmless.
-#define RJ_DPP_STEP(OP, v, ctrl, rmask) v = OP(v, __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false))
-__device__ __forceinline__ int32_t rj_min32(int32_t a, int32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ int32_t rj_max32(int32_t a, int32_t b) { return a > b ? a : b; }
+// (The DPP operand rides inside the min / max / or itself: six VALU instructions per reduction.  Through
+// __builtin_amdgcn_update_dpp the compiler emits a copy, a v_mov_b32_dpp and the operation -- 18.  A VGPR written by a
+// VALU instruction needs two wait states before a DPP instruction reads it: s_nop 1 between the dependent steps.)
+#define RJ_DPP_REDUCE(OP, v)                                                                           \
+  asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
+               OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+               OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                          \
+               OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                          \
+               OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                       \
+               OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"                                       \
+               : "+v"(v))
 __device__ __forceinline__ int32_t wave_min(int32_t v) {
-  RJ_DPP_STEP(rj_min32, v, 0xb1, 0xf);   // quad_perm:[1,0,3,2]
-  RJ_DPP_STEP(rj_min32, v, 0x4e, 0xf);   // quad_perm:[2,3,0,1]
-  RJ_DPP_STEP(rj_min32, v, 0x124, 0xf);  // row_ror:4
-  RJ_DPP_STEP(rj_min32, v, 0x128, 0xf);  // row_ror:8
-  RJ_DPP_STEP(rj_min32, v, 0x142, 0xa);  // row_bcast:15 into rows 1 and 3
-  RJ_DPP_STEP(rj_min32, v, 0x143, 0xc);  // row_bcast:31 into rows 2 and 3
+  RJ_DPP_REDUCE("v_min_i32_dpp", v);
   return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int32_t wave_max(int32_t v) {
-  RJ_DPP_STEP(rj_max32, v, 0xb1, 0xf);
-  RJ_DPP_STEP(rj_max32, v, 0x4e, 0xf);
-  RJ_DPP_STEP(rj_max32, v, 0x124, 0xf);
-  RJ_DPP_STEP(rj_max32, v, 0x128, 0xf);
-  RJ_DPP_STEP(rj_max32, v, 0x142, 0xa);
-  RJ_DPP_STEP(rj_max32, v, 0x143, 0xc);
+  RJ_DPP_REDUCE("v_max_i32_dpp", v);
   return __builtin_amdgcn_readlane(v, 63);
 }
-__device__ __forceinline__ uint32_t rj_or32(uint32_t a, uint32_t b) { return a | b; }
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
-  RJ_DPP_STEP(rj_or32, v, 0xb1, 0xf);
-  RJ_DPP_STEP(rj_or32, v, 0x4e, 0xf);
-  RJ_DPP_STEP(rj_or32, v, 0x124, 0xf);
-  RJ_DPP_STEP(rj_or32, v, 0x128, 0xf);
-  RJ_DPP_STEP(rj_or32, v, 0x142, 0xa);
-  RJ_DPP_STEP(rj_or32, v, 0x143, 0xc);
-  return __builtin_amdgcn_readlane(v, 63);
+  RJ_DPP_REDUCE("v_or_b32_dpp", v);
+  return (uint32_t) __builtin_amdgcn_readlane((int32_t) v, 63);
 }
-#undef RJ_DPP_STEP
+// three reductions side by side (min, max, min): each step's three instructions are independent, so they are
+// one another's wait states -- 18 VALU instructions and no s_nop for what a query group's head needs
+__device__ __forceinline__ void wave_min_max_min(int32_t& a, int32_t& b, int32_t& c) {
+#define RJ_DPP3(ctrl)                                       \
+  "v_min_i32_dpp %0, %0, %0 " ctrl " bank_mask:0xf\n\t"      \
+  "v_max_i32_dpp %1, %1, %1 " ctrl " bank_mask:0xf\n\t"      \
+  "v_min_i32_dpp %2, %2, %2 " ctrl " bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" RJ_DPP3("quad_perm:[1,0,3,2] row_mask:0xf") RJ_DPP3("quad_perm:[2,3,0,1] row_mask:0xf")
+               RJ_DPP3("row_ror:4 row_mask:0xf") RJ_DPP3("row_ror:8 row_mask:0xf") RJ_DPP3("row_bcast:15 row_mask:0xa")
+               RJ_DPP3("row_bcast:31 row_mask:0xc")
+               : "+v"(a), "+v"(b), "+v"(c));
+#undef RJ_DPP3
+  a = __builtin_amdgcn_readlane(a, 63);
+  b = __builtin_amdgcn_readlane(b, 63);
+  c = __builtin_amdgcn_readlane(c, 63);
+}
+#undef RJ_DPP_REDUCE
 __device__ __forceinline__ int32_t bcast(int32_t v, int src_lane_uniform) {
   return __builtin_amdgcn_readlane(v, src_lane_uniform);
 }

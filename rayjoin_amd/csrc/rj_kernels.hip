@@ -1165,6 +1165,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
   const int stack_cap = walk_stack_entries(T.top);
   uint4* const stack = walk_smem + (size_t) wib * (walk_wave_lds(T.top) / 16);
   uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [kWalkList][64], bank = lane
+  const uint32_t stack_lds = (uint32_t) (uintptr_t) stack;  // the stack's LDS byte address (the low half of the generic pointer)
   const uint32_t GL = A.group_lanes;
   const uint64_t ngroups = (A.n + GL - 1) / GL;
   const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
@@ -1194,9 +1195,8 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
       qy = quant(p.y);
     }
     const int32_t qym1 = qy > 0 ? qy - 1 : 0;
-    const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
-    const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
-    const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
+    int32_t gx0 = valid ? qx : kEmptyMin, gx1 = valid ? qx : kEmptyMax, gy0 = valid ? qy : kEmptyMin;
+    wave_min_max_min(gx0, gx1, gy0);
     int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer (-1: the lane sits out)
     int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
     // This lane's candidate list is cand[lane + 64 k] (bank = lane); `cand_at` = where the next one goes, so the fill
@@ -1232,8 +1232,11 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     while (sp > 0) {
       // every lane reads the same entry (an LDS broadcast): the staleness test runs on those registers as they
       // are, only the node id moves to the scalar side
-      const uint4 ent = stack[sp - 1];
+      // (one ds_read_b128 at one computed address: left to itself the compiler reads the entry in three pieces
+      //  behind three address computations -- 4 of the pop's 10 VALU instructions, and a group pops 19 entries)
       --sp;
+      uint4 ent;
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ent) : "v"(stack_lds + (uint32_t) sp * 16u) : "memory");
       const int32_t ey0 = (int32_t) ent.y, ex0 = (int32_t) ent.z, ex1 = (int32_t) ent.w;
       const bool want = ((qx - ex0) | (ex1 - qx) | (qbest - ey0)) >= 0;  // stale entries die here, untouched
       if (!__ballot(want)) {
