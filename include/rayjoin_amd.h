@@ -250,10 +250,12 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * wave at a time; 0 = automatic, the default: 8 for LSI, 6 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
  * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
  * "leaf_order" 1 (default; environment RJ_LEAF_ORDER=0 changes it) / 0: what the NEXT rj_build_lbvh makes a leaf of --
- * 1: a run of <= 64 consecutive edges of one polyline (a long chain cut into near-equal pieces, short chains packed
- * while each continues the one before), the analogue of the reference's RT grouping (src/rt/primitive.h:120-260),
- * unless that would leave the leaves less than 40 % full (maps of tiny unrelated chains), 0: 64 neighbours along the
- * Hilbert curve; rj_get_option "leaf_order_used0/1" says what the index of map 0 / 1 was built with, "leaf_slots0/1" its size;
+ * 1: a run of <= 64 consecutive edges of one POLYLINE, the analogue of the reference's RT grouping
+ * (src/rt/primitive.h:120-260): chains are stitched through their shared end points by straightest continuation, the
+ * polylines cut into near-equal runs (<= 32 edges where the map's chains average fewer than 16), once per uploaded map on
+ * the host, the first time such an index is built -- unless the leaves would be less than 40 % full (isolated polygons of a
+ * few edges); 0: 64 neighbours along the Hilbert curve.  Results never depend on it.  rj_get_option "leaf_order_used0/1"
+ * says what the index of map 0 / 1 was built with, "leaf_slots0/1" its size in slots (64 per leaf);
  * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
  * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
  * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;

@@ -28,7 +28,11 @@ struct MapState {
   uint32_t* left = nullptr;
   uint32_t* right = nullptr;
   std::vector<uint32_t> h_edge_begin;  // host copy of the first eid of every chain (+ sentinel): "leaf_order" 1 cuts its runs from it
-  std::vector<uint32_t> h_runs;        // chain_runs() of this map, cut once at upload (part of the load phase, like the segment build)
+  // "leaf_order" 1: the polyline runs of this map (stitch_runs), cut on the host the first time an index of it is
+  // built and kept on the device: piece p = eids [piece_begin[p], + piece_len[p]), run r = pieces [run_first[r], run_first[r + 1])
+  bool runs_cut = false;
+  uint64_t nruns = 0, npieces = 0;
+  uint32_t *piece_begin = nullptr, *piece_len = nullptr, *run_first = nullptr;
 };
 
 struct BvhState {
@@ -205,41 +209,135 @@ int dev_alloc(rj_handle h, T** p, uint64_t count) {
 
 void free_map(MapState& m) {
   (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.ccode); (void) hipFree(m.left); (void) hipFree(m.right);
+  (void) hipFree(m.piece_begin); (void) hipFree(m.piece_len); (void) hipFree(m.run_first);
   m = MapState();
 }
 
 // Chain-run leaves (the reference's RT grouping: src/rt/primitive.h:120-260, rt_lsi_custom.cu:31-44):
-// a leaf = a run of consecutive eids that form ONE polyline -- a long chain is cut into ceil(len / 64) near-equal
-// pieces; short chains that follow each other in the file are packed together while they fit AND each starts where
-// the one before ended (a polyline cut at every junction, like the lattice stand-ins' rows).  Chains that merely
-// follow each other in the file are not packed: a leaf of unrelated chains has a box as large as their distance
-// (measured: 5x slower PIP on the WaterBodies stand-in at its row ends, 4 orders of magnitude on the gaussian
-// polygons, whose file order is random).  -> run_begin[nruns + 1]
-std::vector<uint32_t> chain_runs(const std::vector<uint32_t>& edge_begin, const std::vector<int64_t>& ends) {
-  std::vector<uint32_t> rb;
-  const size_t nc = edge_begin.empty() ? 0 : edge_begin.size() - 1;
-  uint32_t open_begin = 0, open_len = 0;  // the pack of short chains being filled
-  size_t open_last = 0;                   // ... and its last chain
-  for (size_t c = 0; c < nc; c++) {
-    const uint32_t b = edge_begin[c], len = edge_begin[c + 1] - b;
-    if (len == 0) continue;
-    const bool continues = open_len && ends[4 * open_last + 2] == ends[4 * c] && ends[4 * open_last + 3] == ends[4 * c + 1];
-    if (open_len && (len > 64 || open_len + len > 64 || !continues)) {
-      rb.push_back(open_begin);
-      open_len = 0;
-    }
-    if (len > 64) {
-      const uint32_t k = (len + 63) / 64;
-      for (uint32_t i = 0; i < k; i++) rb.push_back(b + (uint32_t) ((uint64_t) len * i / k));
-    } else {
-      if (!open_len) open_begin = b;
-      open_len += len;
-      open_last = c;
+// a leaf = a run of <= 64 consecutive edges of ONE POLYLINE.  A CDB chain ends at every junction, so a polyline is
+// stitched through the junctions first: at every shared end point the incident chains are paired by straightest
+// continuation (smallest cosine between their directions there, at most 120 degrees of turn), the pairs are followed
+// into paths -- a lattice row, a river, a county line -- and every path is cut into ceil(len / 64) near-equal runs.
+// A run is then a list of pieces (eid ranges of the chains it crosses; a chain walked backwards contributes the same
+// eids, the order inside a leaf is free).  Chains that merely follow each other in the FILE are never joined: a leaf of
+// unrelated chains has a box as large as their distance (measured: PIP 1.9 -> 8.2 ms on the WaterBodies stand-in at
+// its row ends, 4 orders of magnitude on the gaussian polygons, whose file order is random).
+// Host code, once per uploaded map (the first rj_build_lbvh that wants it): O(chains) with a hash of the end points.
+struct RunSet {
+  std::vector<uint32_t> piece_begin, piece_len, run_first;  // run_first[nruns + 1]
+};
+
+RunSet stitch_runs(const int64_t* xy, const std::vector<uint32_t>& eb, uint64_t cap_edges) {
+  RunSet R;
+  const size_t nc = eb.empty() ? 0 : eb.size() - 1;
+  constexpr uint32_t kNone = 0xFFFFFFFFu;
+  // incidence i = 2 c + end (0: the chain's first point, 1: its last); the point indices of chain c: first = eb[c] + c
+  auto first_pt = [&](size_t c) { return (uint64_t) eb[c] + c; };
+  auto last_pt = [&](size_t c) { return (uint64_t) eb[c + 1] + c; };
+  // 1. nodes: open-addressing hash of the end points -> head of that node's incidence list
+  size_t cap = 16;
+  while (cap < 4 * nc + 16) cap <<= 1;
+  std::vector<uint32_t> slot_head(cap, kNone);  // first incidence of the node living in this slot
+  std::vector<uint32_t> inc_next(2 * nc, kNone), inc_node(2 * nc, kNone);
+  auto end_xy = [&](uint32_t i, int64_t& x, int64_t& y) {
+    const uint64_t p = (i & 1) ? last_pt(i >> 1) : first_pt(i >> 1);
+    x = xy[2 * p]; y = xy[2 * p + 1];
+  };
+  for (uint32_t i = 0; i < 2 * nc; i++) {
+    if (eb[(i >> 1) + 1] == eb[i >> 1]) continue;  // (an empty chain: cannot happen after rj_upload_map's checks)
+    int64_t x, y;
+    end_xy(i, x, y);
+    uint64_t hsh = ((uint64_t) x * 0x9E3779B97F4A7C15ull) ^ (((uint64_t) y + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full);
+    hsh ^= hsh >> 29;
+    size_t sl = (size_t) hsh & (cap - 1);
+    for (;;) {
+      const uint32_t head = slot_head[sl];
+      if (head == kNone) { slot_head[sl] = i; inc_node[i] = (uint32_t) sl; break; }
+      int64_t hx, hy;
+      end_xy(head, hx, hy);
+      if (hx == x && hy == y) { inc_next[i] = head; slot_head[sl] = i; inc_node[i] = (uint32_t) sl; break; }
+      sl = (sl + 1) & (cap - 1);
     }
   }
-  if (open_len) rb.push_back(open_begin);
-  rb.push_back(nc ? edge_begin[nc] : 0);
-  return rb;
+  // 2. pair the incidences of every node by straightest continuation
+  std::vector<uint32_t> partner(2 * nc, kNone);
+  std::vector<uint32_t> at;
+  std::vector<double> dx, dy;
+  for (size_t sl = 0; sl < cap; sl++) {
+    if (slot_head[sl] == kNone) continue;
+    at.clear(); dx.clear(); dy.clear();
+    for (uint32_t i = slot_head[sl]; i != kNone; i = inc_next[i]) {
+      const size_t c = i >> 1;
+      int64_t x0, y0, x1, y1;
+      end_xy(i, x0, y0);
+      end_xy(i ^ 1, x1, y1);
+      if (x0 == x1 && y0 == y1) continue;  // a closed chain (a polygon): it starts and ends here, nothing to continue
+      const uint64_t q = (i & 1) ? last_pt(c) - 1 : first_pt(c) + 1;  // the vertex next to this end, inside the chain
+      double vx = (double) (xy[2 * q] - x0), vy = (double) (xy[2 * q + 1] - y0);
+      const double n = std::sqrt(vx * vx + vy * vy);
+      if (n == 0) continue;
+      at.push_back(i); dx.push_back(vx / n); dy.push_back(vy / n);
+    }
+    if (at.size() < 2 || at.size() > 16) continue;  // (a hub of more than 16 chains: leave them be)
+    bool used[16] = {false};
+    for (;;) {
+      double best = -0.5;  // cos of the angle between the two directions AWAY from the node: -1 = straight on
+      int bi = -1, bj = -1;
+      for (size_t u = 0; u < at.size(); u++)
+        for (size_t v = u + 1; v < at.size(); v++) {
+          if (used[u] || used[v] || (at[u] >> 1) == (at[v] >> 1)) continue;
+          const double d = dx[u] * dx[v] + dy[u] * dy[v];
+          if (d < best) { best = d; bi = (int) u; bj = (int) v; }
+        }
+      if (bi < 0) break;
+      used[bi] = used[bj] = true;
+      partner[at[bi]] = at[bj];
+      partner[at[bj]] = at[bi];
+    }
+  }
+  // 3. follow the pairs into paths, cut every path into near-equal runs of <= 64 edges
+  std::vector<bool> visited(nc, false);
+  std::vector<uint32_t> path;  // incidences through which the path ENTERS its chains
+  R.run_first.push_back(0);
+  auto emit = [&]() {
+    uint64_t total = 0;
+    for (uint32_t i : path) total += eb[(i >> 1) + 1] - eb[i >> 1];
+    if (!total) return;
+    const uint64_t k = (total + cap_edges - 1) / cap_edges;
+    uint64_t run = 0, done = 0, run_end = total / k;  // run `run` covers path positions [total run / k, total (run + 1) / k)
+    for (uint32_t i : path) {
+      const size_t c = i >> 1;
+      const uint32_t len = eb[c + 1] - eb[c];
+      uint32_t used_c = 0;  // edges of this chain already handed out, counted from the end the path entered by
+      while (used_c < len) {
+        const uint32_t take = (uint32_t) std::min<uint64_t>(len - used_c, run_end - done);
+        // entered at its first point: the next `take` eids from the front; at its last point: from the back
+        R.piece_begin.push_back((i & 1) ? eb[c + 1] - used_c - take : eb[c] + used_c);
+        R.piece_len.push_back(take);
+        used_c += take;
+        done += take;
+        if (done == run_end && done < total) {
+          R.run_first.push_back((uint32_t) R.piece_begin.size());
+          run++;
+          run_end = total * (run + 1) / k;
+        }
+      }
+    }
+    R.run_first.push_back((uint32_t) R.piece_begin.size());
+  };
+  auto walk = [&](uint32_t enter) {
+    path.clear();
+    for (uint32_t i = enter; i != kNone && !visited[i >> 1]; i = partner[i ^ 1]) {
+      visited[i >> 1] = true;
+      path.push_back(i);
+    }
+    emit();
+  };
+  for (uint32_t i = 0; i < 2 * nc; i++)  // paths start at an end that continues nothing
+    if (partner[i] == kNone && !visited[i >> 1] && eb[(i >> 1) + 1] > eb[i >> 1]) walk(i);
+  for (uint32_t i = 0; i < 2 * nc; i += 2)  // what is left are closed loops of paired chains
+    if (!visited[i >> 1] && eb[(i >> 1) + 1] > eb[i >> 1]) walk(i);
+  return R;
 }
 
 void free_grid(GridState& g) {
@@ -601,15 +699,6 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (rc || e != hipSuccess) free_map(m);  // no half-uploaded map
   if (rc) return rc;
   RJ_HIP(h, e);
-  {  // the runs "leaf_order" 1 makes leaves of (which chains continue each other is read off the host arrays here)
-    std::vector<int64_t> ends(4 * nc);
-    for (uint64_t c = 0; c < nc; c++) {
-      const uint64_t f = row_index[c], l = row_index[c + 1] - 1;
-      ends[4 * c] = xy[2 * f]; ends[4 * c + 1] = xy[2 * f + 1];
-      ends[4 * c + 2] = xy[2 * l]; ends[4 * c + 3] = xy[2 * l + 1];
-    }
-    m.h_runs = chain_runs(eb, ends);
-  }
   m.h_edge_begin = std::move(eb);
   m.present = true;
   return RJ_OK;
@@ -694,11 +783,33 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   const MapState& m = h->map[base_map_id];
   BvhState& b = h->bvh[base_map_id];
   // "leaf_order" 1: the leaves are runs of consecutive eids, cut on the host from the chain layout
-  // (a map of short chains that do not continue each other -- polygons of a few edges -- would leave its leaves
-  //  mostly empty: above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
-  static const std::vector<uint32_t> no_runs;
-  const std::vector<uint32_t>& runs = (h->leaf_order == 1 && m.ne && !m.h_runs.empty() && (m.h_runs.size() - 1) * 64 <= m.ne * 5 / 2) ? m.h_runs : no_runs;
-  const uint64_t nruns = runs.empty() ? 0 : runs.size() - 1;
+  if (h->leaf_order == 1 && m.ne && !h->map[base_map_id].runs_cut) {
+    // the first index of this map that wants polyline runs: fetch the points, stitch and cut on the host, keep the
+    // pieces on the device (a later rebuild only sorts the runs)
+    MapState& mm = h->map[base_map_id];
+    std::vector<int64_t> xy(2 * mm.np);
+    RJ_HIP(h, hipMemcpy(xy.data(), mm.pts, 16 * mm.np, hipMemcpyDeviceToHost));
+    // How long a run may be.  A full leaf (64 edges) is right where chains are long: the strip is a piece of one smooth
+    // line.  A polyline stitched from many SHORT chains wiggles through a junction every few edges, its strip is fat,
+    // and where it runs steeply all of its edges overlap in x -- the in-leaf scans (x-sorted slots) then test every
+    // slot.  Half-full leaves of 32 edges measured better there on BOTH kernels (WaterBodies stand-in, 10-edge chains:
+    // k_lsi 1.29 vs 1.49 ms with 64, 1.37 Hilbert; PIP 1.75 vs 1.88 / 1.88) and worse where chains are long (USCounty:
+    // PIP 0.87 vs 0.74): the cap follows the mean chain length.
+    const uint64_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
+    const RunSet R = stitch_runs(xy.data(), mm.h_edge_begin, cap_edges);
+    mm.runs_cut = true;
+    mm.nruns = R.run_first.size() - 1;
+    mm.npieces = R.piece_begin.size();
+    if (int r = dev_alloc(h, &mm.piece_begin, mm.npieces)) return r;
+    if (int r = dev_alloc(h, &mm.piece_len, mm.npieces)) return r;
+    if (int r = dev_alloc(h, &mm.run_first, mm.nruns + 1)) return r;
+    RJ_HIP(h, hipMemcpy(mm.piece_begin, R.piece_begin.data(), 4 * mm.npieces, hipMemcpyHostToDevice));
+    RJ_HIP(h, hipMemcpy(mm.piece_len, R.piece_len.data(), 4 * mm.npieces, hipMemcpyHostToDevice));
+    RJ_HIP(h, hipMemcpy(mm.run_first, R.run_first.data(), 4 * (mm.nruns + 1), hipMemcpyHostToDevice));
+  }
+  // (a map of short polylines -- polygons of a few edges that touch nothing -- would leave its leaves mostly empty:
+  //  above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
+  const uint64_t nruns = (h->leaf_order == 1 && m.ne && m.runs_cut && m.nruns * 64 <= m.ne * 5 / 2) ? m.nruns : 0;
   const uint64_t n0p_new = nruns ? nruns * 64 : pad64(m.ne ? m.ne : 1);
   if (n0p_new >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_build_lbvh: %llu leaf slots do not fit 32-bit slot ids", (unsigned long long) n0p_new);
   const bool reuse = b.sseg && b.n0p == n0p_new;  // rebuild of a same-sized map: keep the buffers
@@ -739,16 +850,11 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     if (int r = ensure_sort_scratch(h, m.ne)) return r;
   MortonKey *k_in = h->ord_kin, *k_out = h->ord_kout;
   uint32_t *v_in = h->ord_vin, *v_out = h->ord_vout;
-  uint32_t* d_runs = nullptr;
-  if (nruns) {
-    if (int r = dev_alloc(h, &d_runs, nruns + 1)) return r;
-  }
   hipError_t e = hipSuccess;
   do {
     tic(h, RJ_T_BUILD_KEYS);
     if (nruns) {
-      if ((e = hipMemcpyAsync(d_runs, runs.data(), 4 * (nruns + 1), hipMemcpyHostToDevice, h->stream)) != hipSuccess) break;
-      if ((e = launch_run_keys(h->stream, m.seg, d_runs, nruns, k_in, v_in)) != hipSuccess) break;
+      if ((e = launch_run_keys(h->stream, m.seg, m.piece_begin, m.piece_len, m.run_first, nruns, k_in, v_in)) != hipSuccess) break;
     } else if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_KEYS);
     tic(h, RJ_T_BUILD_SORT);
@@ -759,7 +865,8 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     toc(h, RJ_T_BUILD_SORT);
     tic(h, RJ_T_BUILD_LEAVES);
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
-    if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, d_runs, b.n0p / 64, b.alloc[1],
+    if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, nruns ? m.piece_begin : nullptr,
+                                 m.piece_len, m.run_first, b.n0p / 64, b.alloc[1],
                                  b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
@@ -778,8 +885,6 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     toc(h, RJ_T_BUILD);
     e = hipStreamSynchronize(h->stream);
   } while (0);
-  if (e != hipSuccess) (void) hipStreamSynchronize(h->stream);  // (d_runs and the host vector may still be read)
-  (void) hipFree(d_runs);
   RJ_HIP(h, e);
   b.built = true;
   co_reset(h);

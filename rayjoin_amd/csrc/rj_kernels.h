@@ -104,9 +104,11 @@ hipError_t launch_xsect_gather(hipStream_t st, const XsectRec* in, const uint32_
 hipError_t launch_xsect_order_runs(hipStream_t st, XsectRec* rec, uint64_t n, int im, const Seg* seg_im, int64_t* midpts);
 hipError_t launch_xsect_set_mid(hipStream_t st, XsectRec* rec, uint64_t n, int im, const int32_t* face);
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
-hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* run_begin, uint64_t nruns, MortonKey* keys, uint32_t* vals);
+hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* piece_begin, const uint32_t* piece_len, const uint32_t* run_first,
+                           uint64_t nruns, MortonKey* keys, uint32_t* vals);
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
-                               const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* run_begin, uint64_t nblocks,
+                               const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
+                               const uint32_t* piece_len, const uint32_t* run_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
                                int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ);
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);

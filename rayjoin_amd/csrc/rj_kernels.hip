@@ -99,11 +99,13 @@ __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uin
   }
 }
 
-// Chain-run leaves: the sort key of a run = the Hilbert key of its middle segment's midpoint
-__global__ __launch_bounds__(256) void k_run_keys(const Seg* __restrict__ seg, const uint32_t* __restrict__ run_begin, uint64_t nruns,
-                                                  MortonKey* __restrict__ keys, uint32_t* __restrict__ vals) {
+// Polyline-run leaves: the sort key of a run = the Hilbert key of the midpoint of the middle edge of its middle piece
+__global__ __launch_bounds__(256) void k_run_keys(const Seg* __restrict__ seg, const uint32_t* __restrict__ piece_begin,
+                                                  const uint32_t* __restrict__ piece_len, const uint32_t* __restrict__ run_first,
+                                                  uint64_t nruns, MortonKey* __restrict__ keys, uint32_t* __restrict__ vals) {
   for (uint64_t r = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; r < nruns; r += (uint64_t) gridDim.x * blockDim.x) {
-    const Seg s = seg[(run_begin[r] + run_begin[r + 1]) >> 1];
+    const uint32_t p = (run_first[r] + run_first[r + 1]) >> 1;
+    const Seg s = seg[piece_begin[p] + (piece_len[p] >> 1)];
     const uint64_t mx = (uint64_t) (((s.x1 + s.x2) >> 1) + kCoordOffset), my = (uint64_t) (((s.y1 + s.y2) >> 1) + kCoordOffset);
     keys[r] = (MortonKey) hilbert16((uint32_t) (mx >> 31), (uint32_t) (my >> 31));
     vals[r] = (uint32_t) r;
@@ -198,7 +200,9 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       const uint32_t* __restrict__ edge_chain,
                                                       const uint32_t* __restrict__ left,
                                                       const uint32_t* __restrict__ right, uint64_t ne,
-                                                      const uint32_t* __restrict__ run_begin,
+                                                      const uint32_t* __restrict__ piece_begin,
+                                                      const uint32_t* __restrict__ piece_len,
+                                                      const uint32_t* __restrict__ run_first,
                                                       uint64_t nblocks, uint64_t n_parent_alloc,
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
@@ -220,13 +224,21 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
     uint32_t id = 0xFFFFFFFFu;
     int32_t fc = 0;
-    // Hilbert leaves: the block's segments are 64 neighbours of the sorted order.  Chain-run leaves ("leaf_order" 1):
-    // the block is one run of consecutive eids (a piece of a chain, or a few whole short chains), `order` sorts the runs.
+    // Hilbert leaves: the block's segments are 64 neighbours of the sorted order.  Polyline-run leaves ("leaf_order" 1):
+    // the block is one run (<= 64 edges in a few pieces: eid ranges of the chains the polyline crosses), `order` sorts the runs.
     bool valid = i < ne;
-    if (run_begin) {
-      const uint32_t r = order[blk], rb = run_begin[r];
-      valid = (uint32_t) lane < run_begin[r + 1] - rb;
-      if (valid) id = rb + (uint32_t) lane;
+    if (piece_begin) {
+      const uint32_t r = order[blk];
+      valid = false;
+      uint32_t acc = 0;
+      for (uint32_t p = run_first[r]; p < run_first[r + 1]; p++) {  // (wave-uniform bounds and loads; a handful of pieces)
+        const uint32_t len = piece_len[p];
+        if (!valid && (uint32_t) lane < acc + len) {
+          valid = true;
+          id = piece_begin[p] + ((uint32_t) lane - acc);
+        }
+        acc += len;
+      }
     } else if (valid) {
       id = __builtin_nontemporal_load(&order[i]);
     }
@@ -1552,18 +1564,20 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {
   return hipGetLastError();
 }
 
-hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* run_begin, uint64_t nruns, MortonKey* keys, uint32_t* vals) {
+hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* piece_begin, const uint32_t* piece_len, const uint32_t* run_first,
+                           uint64_t nruns, MortonKey* keys, uint32_t* vals) {
   if (nruns == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_run_keys, dim3(grid_for(nruns, 256, 8192)), dim3(256), 0, st, seg, run_begin, nruns, keys, vals);
+  hipLaunchKernelGGL(k_run_keys, dim3(grid_for(nruns, 256, 8192)), dim3(256), 0, st, seg, piece_begin, piece_len, run_first, nruns, keys, vals);
   return hipGetLastError();
 }
 
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
-                               const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* run_begin, uint64_t nblocks,
+                               const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
+                               const uint32_t* piece_len, const uint32_t* run_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
                                int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, run_begin, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
+                     left, right, ne, piece_begin, piece_len, run_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
   return hipGetLastError();
 }
 
