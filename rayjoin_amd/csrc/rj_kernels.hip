@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     // Order is irrelevant for LSI (nothing prunes), so the stack is consumed two entries at a time
     // with both entries' boxes requested before either is processed: two dependent-load chains in
     // flight per wave instead of one (the kernel is bound by the latency of these loads).
-    auto process = [&](uint32_t e, const QBox& b, int32_t pm) {
+    auto process = [&](uint32_t e, const QBox& b, const uint2& tab) {
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
       const long long tk0 = STATS ? clock64() : 0;
@@ -670,23 +670,32 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         wave_lds_fence();
         if (STATS) tk_node += clock64() - tk0;
       } else {
-        // leaf block: 64 base segments sorted by x0, one per lane.  Each query lane binary-searches
-        // the prefix with x0 <= its x1 and scans it backwards while pmx1 says an x-overlap is
-        // still possible.
+        // leaf block: 64 base segments sorted by x0, one per lane.  The block's x-bucket table (k_build_leaves) gives
+        // the slots [lo, hi) that can overlap the query's x-range -- hi from the bucket of its right end, lo from the
+        // bucket of its left end -- instead of a 64-wide cross-lane binary search and a prefix-max fetch per step: four
+        // dependent LDS round trips less per visit in a kernel that is bound by exactly such chains.  The block's
+        // x-extent (what the table was built on) is re-derived from its boxes: padding slots are empty boxes.
         const uint32_t slot0 = idx * 64;
         if (STATS) st_leaf++;
-        int j = wave_upper_bound(b.x0, qx1) - 1;  // invalid lanes: qx1 = -1 -> j = -1
-        for (;;) {
-          const int jj = j < 0 ? 0 : j;
-          const int32_t pmj = __shfl(pm, jj, 64);
-          const bool act = j >= 0 && pmj >= qx0;
-          if (!__ballot(act)) break;
-          const int32_t sx1 = __shfl(b.x1, jj, 64), sy0 = __shfl(b.y0, jj, 64), sy1 = __shfl(b.y1, jj, 64);
-          const bool c = act && sx1 >= qx0 && qy0 <= sy1 && sy0 <= qy1;  // (x0[j] <= qx1 by construction)
+        const int32_t lx0 = wave_min(b.x0), lx1 = wave_max(b.x1);
+        const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
+        const int32_t ca = qx0 > lx0 ? qx0 : lx0, cz = qx1 < lx1 ? qx1 : lx1;  // the query's x-range inside the block's
+        const bool some = ca <= cz;                                           // (idle lanes: qx0 > qx1)
+        const uint32_t bhi = some ? (uint32_t) (cz - lx0) >> sh : 0u, blo = some ? (uint32_t) (ca - lx0) >> sh : 0u;
+        const uint32_t hi = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (bhi >> 2) << 2, (int) tab.x) >> ((bhi & 3u) * 8u)) & 0xFFu;
+        const uint32_t lo = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (blo >> 2) << 2, (int) tab.y) >> ((blo & 3u) * 8u)) & 0xFFu;
+        int j = some ? (int) hi - 1 : -1;
+        const int jlo = some ? (int) lo : 0;
+        while (__ballot(j >= jlo)) {
+          const int ja = j << 2;  // (ds_bpermute takes the lane from bits 7:2 of the address; a lane past its range reads some slot, harmlessly)
+          const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, b.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, b.x1);
+          const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, b.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, b.y1);
+          // box overlap and "still inside my range" as one sign test
+          const bool c = ((qx1 - sx0) | (sx1 - qx0) | (qy1 - sy0) | (sy1 - qy0) | (j - jlo)) >= 0;
           const uint64_t cm = __ballot(c);
           if (STATS) st_box++;
           if (cm) {
-            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q, slot0 + (uint32_t) jj);
+            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q, slot0 + (uint32_t) (j & 63));
             np += __popcll(cm);
             wave_lds_fence();
             if (np >= 64) lsi_drain<STATS>(L, np, nh, 64, A, lane, st_tests);
@@ -696,13 +705,13 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         if (STATS) tk_leaf += clock64() - tk0;
       }
     };
-    auto fetch = [&](uint32_t e, QBox& b, int32_t& pm) {
+    auto fetch = [&](uint32_t e, QBox& b, uint2& tab) {
       const int lvl = (int) (e >> 28);
       const uint64_t c = (uint64_t) (e & 0x0FFFFFFFu) * 64 + lane;
-      // one address for both kinds of entry keeps the loads branch-free (pmx1 is only meaningful for leaves)
+      // one address for both kinds of entry keeps the loads branch-free (the bucket table is only meaningful for leaves)
       const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
       b = src[c];
-      pm = T.pmx1[lvl > 1 ? (uint64_t) lane : c];
+      tab = T.xtab[lvl > 1 ? (uint64_t) lane : c];
     };
     while (sp > 0) {
       const bool two = sp > 1;
@@ -710,11 +719,11 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       const uint32_t eb = __builtin_amdgcn_readfirstlane(L.stack[two ? sp - 2 : sp - 1]);
       sp -= two ? 2 : 1;
       QBox ba, bb2;
-      int32_t pma, pmb;
-      fetch(ea, ba, pma);
-      fetch(eb, bb2, pmb);
-      process(ea, ba, pma);
-      if (two) process(eb, bb2, pmb);
+      uint2 ta, tb;
+      fetch(ea, ba, ta);
+      fetch(eb, bb2, tb);
+      process(ea, ba, ta);
+      if (two) process(eb, bb2, tb);
     }
   }
   }
