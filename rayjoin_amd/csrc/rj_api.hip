@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rayjoin_amd.h"
@@ -234,66 +235,80 @@ RunSet stitch_runs(const int64_t* xy, const std::vector<uint32_t>& eb, uint64_t 
   // incidence i = 2 c + end (0: the chain's first point, 1: its last); the point indices of chain c: first = eb[c] + c
   auto first_pt = [&](size_t c) { return (uint64_t) eb[c] + c; };
   auto last_pt = [&](size_t c) { return (uint64_t) eb[c + 1] + c; };
-  // 1. nodes: open-addressing hash of the end points -> head of that node's incidence list
-  size_t cap = 16;
-  while (cap < 4 * nc + 16) cap <<= 1;
-  std::vector<uint32_t> slot_head(cap, kNone);  // first incidence of the node living in this slot
-  std::vector<uint32_t> inc_next(2 * nc, kNone), inc_node(2 * nc, kNone);
-  auto end_xy = [&](uint32_t i, int64_t& x, int64_t& y) {
-    const uint64_t p = (i & 1) ? last_pt(i >> 1) : first_pt(i >> 1);
-    x = xy[2 * p]; y = xy[2 * p + 1];
-  };
-  for (uint32_t i = 0; i < 2 * nc; i++) {
-    if (eb[(i >> 1) + 1] == eb[i >> 1]) continue;  // (an empty chain: cannot happen after rj_upload_map's checks)
-    int64_t x, y;
-    end_xy(i, x, y);
-    uint64_t hsh = ((uint64_t) x * 0x9E3779B97F4A7C15ull) ^ (((uint64_t) y + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full);
-    hsh ^= hsh >> 29;
-    size_t sl = (size_t) hsh & (cap - 1);
-    for (;;) {
-      const uint32_t head = slot_head[sl];
-      if (head == kNone) { slot_head[sl] = i; inc_node[i] = (uint32_t) sl; break; }
-      int64_t hx, hy;
-      end_xy(head, hx, hy);
-      if (hx == x && hy == y) { inc_next[i] = head; slot_head[sl] = i; inc_node[i] = (uint32_t) sl; break; }
-      sl = (sl + 1) & (cap - 1);
+  // The end points and the directions of the chains AT their ends, gathered once in chain order (the passes below
+  // touch them at random)
+  std::vector<int64_t> ex(2 * nc), ey(2 * nc);
+  std::vector<float> dirx(2 * nc), diry(2 * nc);
+  std::vector<uint64_t> hsh(2 * nc);
+  for (size_t c = 0; c < nc; c++) {
+    const uint64_t p0 = first_pt(c), p1 = last_pt(c);
+    for (int end = 0; end < 2; end++) {
+      const uint32_t i = (uint32_t) (2 * c + end);
+      const uint64_t p = end ? p1 : p0, q = end ? p1 - 1 : p0 + 1;  // q: the vertex next to this end, inside the chain
+      ex[i] = xy[2 * p]; ey[i] = xy[2 * p + 1];
+      const double vx = (double) (xy[2 * q] - ex[i]), vy = (double) (xy[2 * q + 1] - ey[i]);
+      const double n = std::sqrt(vx * vx + vy * vy);
+      dirx[i] = n > 0 ? (float) (vx / n) : 0.0f;
+      diry[i] = n > 0 ? (float) (vy / n) : 0.0f;
+      uint64_t v = ((uint64_t) ex[i] * 0x9E3779B97F4A7C15ull) ^ (((uint64_t) ey[i] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full);
+      hsh[i] = v ^ (v >> 29);
     }
   }
-  // 2. pair the incidences of every node by straightest continuation
+  // 1 + 2, in parallel over hash partitions (a node lives in exactly one): an open-addressing table of the end points
+  // -> that node's incidence list, then the incidences of every node paired by straightest continuation
   std::vector<uint32_t> partner(2 * nc, kNone);
-  std::vector<uint32_t> at;
-  std::vector<double> dx, dy;
-  for (size_t sl = 0; sl < cap; sl++) {
-    if (slot_head[sl] == kNone) continue;
-    at.clear(); dx.clear(); dy.clear();
-    for (uint32_t i = slot_head[sl]; i != kNone; i = inc_next[i]) {
-      const size_t c = i >> 1;
-      int64_t x0, y0, x1, y1;
-      end_xy(i, x0, y0);
-      end_xy(i ^ 1, x1, y1);
-      if (x0 == x1 && y0 == y1) continue;  // a closed chain (a polygon): it starts and ends here, nothing to continue
-      const uint64_t q = (i & 1) ? last_pt(c) - 1 : first_pt(c) + 1;  // the vertex next to this end, inside the chain
-      double vx = (double) (xy[2 * q] - x0), vy = (double) (xy[2 * q + 1] - y0);
-      const double n = std::sqrt(vx * vx + vy * vy);
-      if (n == 0) continue;
-      at.push_back(i); dx.push_back(vx / n); dy.push_back(vy / n);
+  unsigned nthreads = std::thread::hardware_concurrency();
+  nthreads = nthreads < 1 ? 1 : (nthreads > 16 ? 16 : nthreads);
+  if (nc < 50000) nthreads = 1;
+  auto part = [&](unsigned t) {
+    size_t cap = 16;
+    while (cap < (4 * nc) / nthreads + 16) cap <<= 1;
+    std::vector<uint32_t> slot_head(cap, kNone), inc_next(2 * nc, kNone);
+    for (uint32_t i = 0; i < 2 * nc; i++) {
+      if ((hsh[i] >> 40) % nthreads != t) continue;
+      size_t sl = (size_t) hsh[i] & (cap - 1);
+      for (;;) {
+        const uint32_t head = slot_head[sl];
+        if (head == kNone) { slot_head[sl] = i; break; }
+        if (ex[head] == ex[i] && ey[head] == ey[i]) { inc_next[i] = head; slot_head[sl] = i; break; }
+        sl = (sl + 1) & (cap - 1);
+      }
     }
-    if (at.size() < 2 || at.size() > 16) continue;  // (a hub of more than 16 chains: leave them be)
-    bool used[16] = {false};
-    for (;;) {
-      double best = -0.5;  // cos of the angle between the two directions AWAY from the node: -1 = straight on
-      int bi = -1, bj = -1;
-      for (size_t u = 0; u < at.size(); u++)
-        for (size_t v = u + 1; v < at.size(); v++) {
-          if (used[u] || used[v] || (at[u] >> 1) == (at[v] >> 1)) continue;
-          const double d = dx[u] * dx[v] + dy[u] * dy[v];
-          if (d < best) { best = d; bi = (int) u; bj = (int) v; }
-        }
-      if (bi < 0) break;
-      used[bi] = used[bj] = true;
-      partner[at[bi]] = at[bj];
-      partner[at[bj]] = at[bi];
+    uint32_t at[16];
+    for (size_t sl = 0; sl < cap; sl++) {
+      if (slot_head[sl] == kNone) continue;
+      int n = 0;
+      bool hub = false;
+      for (uint32_t i = slot_head[sl]; i != kNone; i = inc_next[i]) {
+        if (ex[i] == ex[i ^ 1] && ey[i] == ey[i ^ 1]) continue;  // a closed chain (a polygon): it starts and ends here, nothing to continue
+        if (dirx[i] == 0.0f && diry[i] == 0.0f) continue;
+        if (n == 16) { hub = true; break; }                      // a hub of more than 16 chains: leave them be
+        at[n++] = i;
+      }
+      if (hub || n < 2) continue;
+      bool used[16] = {false};
+      for (;;) {
+        float best = -0.5f;  // cos of the angle between the two directions AWAY from the node: -1 = straight on
+        int bi = -1, bj = -1;
+        for (int u = 0; u < n; u++)
+          for (int v = u + 1; v < n; v++) {
+            if (used[u] || used[v] || (at[u] >> 1) == (at[v] >> 1)) continue;
+            const float d = dirx[at[u]] * dirx[at[v]] + diry[at[u]] * diry[at[v]];
+            if (d < best) { best = d; bi = u; bj = v; }
+          }
+        if (bi < 0) break;
+        used[bi] = used[bj] = true;
+        partner[at[bi]] = at[bj];
+        partner[at[bj]] = at[bi];
+      }
     }
+  };
+  if (nthreads == 1) {
+    part(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(part, t);
+    for (auto& th : pool) th.join();
   }
   // 3. follow the pairs into paths, cut every path into near-equal runs of <= 64 edges
   std::vector<bool> visited(nc, false);

@@ -31,7 +31,7 @@ for name in a.maps.split(","):
             wall.append((time.perf_counter() - t0) * 1e3)
             ms.append(h.last_ms(_capi.RJ_T_BUILD))
         out[name]["leaf_order_%d" % order] = {"used": h.get_option("leaf_order_used0"), "first_build_ms": round(ms[0], 3), "build_ms": round(min(ms), 3),
-                                              "wall_ms": round(min(wall), 3), "Msegs_per_s_device": round(m.n_edges / min(ms) / 1e3, 1),
+                                              "wall_ms": round(min(wall), 3), "first_wall_ms": round(wall[0], 3), "Msegs_per_s_device": round(m.n_edges / min(ms) / 1e3, 1),
                                               "slots_per_segment": round(h.get_option("leaf_slots0") / m.n_edges, 3)}
     h.close()
 print(json.dumps(out))
