@@ -25,6 +25,7 @@ gather.  Total work is fixed: "strong" scaling.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -107,6 +108,9 @@ def cpu_baseline(args, ctx, base_name, query_name):
     }
 
 
+DEBUG_PHASES = bool(os.environ.get("RJ_BENCH_STEP_TIMES"))
+
+
 def run_workload(args, env, base_name, query_name, steps, warmup, headline, with_cpu):
     """Times `steps` steps of base |><| query on this rank's shard; rank 0 returns the line (a dict)."""
     torch, dist, dev, world, rank, local_rank = env
@@ -160,7 +164,10 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     lsi_ms, pip_ms, walk_ms, pts_ms = [], [], [], []
     state = {"k": 0}
 
+    phases = []  # debug (RJ_BENCH_STEP_TIMES): host clock at the end of enqueueing / main stream done / all done / timers read
+
     def step(record, with_gather=True):
+        t_begin = time.perf_counter()
         closest = closest2[state["k"] % len(closest2)]
         state["k"] += 1
         # everything is enqueued back to back; the step's single host sync is the count read-back
@@ -179,10 +186,15 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             state["pairs_all"], state["cnt_all"] = ex.finish()
             n = state["cnt_all"][rank]
         else:
+            t_enq = time.perf_counter()
             n = h.lsi_query_finish(cap)
+        t_main = time.perf_counter()
         h.sync()  # joins the PIP kernels, which run on the handle's second stream beside the LSI kernel
+        t_all = time.perf_counter()
         if record:  # (one call for all stages: this sits between two steps)
             ms = h.last_ms_all()
+            if DEBUG_PHASES and world == 1:
+                phases.append((t_begin, t_enq, t_main, t_all, time.perf_counter()))
             lsi_ms.append(ms[_capi.RJ_T_LSI_KERNEL])
             pip_ms.append(ms[_capi.RJ_T_PIP_KERNEL])
             pts_ms.append(ms[_capi.RJ_T_LSI_POINTS])
@@ -201,12 +213,30 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         torch.cuda.synchronize()
 
     def timed(k, with_gather=True):
+        # (the interpreter's cyclic collector stays out of the timed steps: a full collection that happens to fall into
+        #  one -- it walks every container the three workloads' generators left behind -- was a 40 ms step among 2.8 ms ones)
+        gc.disable()
+        try:
+            return timed_steps(k, with_gather)
+        finally:
+            gc.enable()
+
+    def timed_steps(k, with_gather):
         barrier()
         t0 = time.perf_counter()
+        marks = []
         for _ in range(k):
             step(True, with_gather)
+            marks.append(time.perf_counter())
         barrier()
         el = time.perf_counter() - t0
+        if DEBUG_PHASES and rank == 0 and phases:
+            ph = np.array(phases[-k:]) * 1e3
+            print("host phases, mean ms from step begin: enqueued %.3f, main stream done %.3f, all done %.3f, timers read %.3f"
+                  % tuple((ph[:, i] - ph[:, 0]).mean() for i in (1, 2, 3, 4)), file=sys.stderr)
+        if os.environ.get("RJ_BENCH_STEP_TIMES") and rank == 0:  # debug: each step's wall time, to stderr
+            print("step wall ms (%s |><| %s): %s" % (base_name, query_name, " ".join("%.3f" % ((b - a) * 1e3) for a, b in zip([t0] + marks, marks))),
+                  file=sys.stderr)
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -218,6 +248,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     # solo times set the split of the shared schedule -- does not also pay the first touch of every buffer
     h.lsi_query(0, 1, e0, e1, cap, pairs)
     h.pip_query(0, 1, None, p0, p1 - p0, closest2[0], faces)
+    gc.collect()  # (before the warm-up steps, not between them and the timed ones: the GPU's clocks drop while the host collects)
     for _ in range(warmup):
         step(False)
     # the kernel schedule must be settled before anything is timed: four measured pairs do it, i.e. the fifth

@@ -259,16 +259,22 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
  * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
  * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;
+ * "lsi_points_split" -1 (default) / 0 / 1: how rj_lsi_points* produce the records -- 1: k_lsi_points decides each stored
+ * coordinate from one exact floor division (no gcd: 98-99 % of the pairs of map-like data) and k_lsi_points_gcd simplifies
+ * the rational (rational.h:198-203) only for the pairs that declines; 0: k_lsi_points_gcd for every pair, one latency
+ * chain instead of two; -1: two kernels from 384 Ki pairs on, going by the count of the last query when the count is on
+ * the device.  The records never depend on it.  rj_get_option "lsi_points_last_split" / "lsi_points_gcd_pairs" report
+ * the form of the last launch and how many pairs its gcd leg took;
  * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
  * consecutive queries are spatially scattered, e.g. the generated workloads of
  * src/run_query.cu:102-167) / 2 always.   "pip_concurrent" 0 never (default) / 1 always /
  * 2 auto: the caller issues rj_lsi_query_async and rj_pip_query_async in PAIRS (the step of a join:
  * both only read the maps and the index) and the two kernels may run beside each other instead of
- * taking turns: the LSI kernel runs on a reduced grid (1-4 blocks per compute unit: 128 + 736 r blocks per 256
- * units, r = the measured ratio of the two sides' solo times; 1.75 per unit before anything is measured) and the
+ * taking turns: the LSI kernel runs on a reduced grid (1-4 blocks per compute unit, about 2: what fits a unit's
+ * registers beside 6 blocks of the PIP walk, see rj_api.hip co_ratio) and the
  * PIP kernels, on a second stream owned by the handle, fill the rest.  That is faster on some workloads and slower on others,
- * so "auto" measures the first four pairs (taking turns / sharing the chip as above / sharing it with the split
- * corrected by what that showed / beside each other on full grids), keeps the fastest from the fifth pair on -- the reference's
+ * so "auto" measures the first four pairs (taking turns / sharing the chip as above / sharing it with the neighbouring
+ * split on the side that one's imbalance points to / beside each other on full grids), keeps the fastest from the fifth pair on -- the reference's
  * five warm-up queries settle it -- and decides again when the index, a map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
  * rj_lsi_query and a PIP query without an LSI query in flight always use the whole chip.)  The PIP
  * query's inputs must be complete when the call

@@ -93,18 +93,24 @@ struct rj_handle_s {
   bool co_measure = false;    // the pair in flight is complete (LSI + PIP): its span can be read
   bool co_points = false;     // ... and k_lsi_points ran between them
   uint64_t co_n = 0;          // query size the decision was made for
-  // how the chip is split when shared: both sides should end together, so k_lsi's share follows the ratio of the
-  // two sides' solo times seen in the "taking turns" trial, r = (k_lsi + k_lsi_points) / (the PIP kernels).  Swept per
-  // pair with tools/share_probe.py (profiles/r03_share_sweep.txt; optimum k_lsi grid at r): Zipcode 0.44 -> 448,
-  // headline 0.46 -> 448-512, nested 0.80 -> 576-704, WaterBodies 0.92 -> 832 blocks of 256 CUs' worth:
-  // 128 + 736 r, within 2 % of the best step on all four.  The PIP side (launched second) fills what is left.
+  // how the chip is split when shared.  Both kernels are persistent, so what counts is what fits a CU together: the
+  // register file takes 6 walk blocks + 2 k_lsi blocks, and that is where the step is shortest wherever the walk may keep
+  // 8 blocks per CU (tree of <= 4 levels); where LDS limits it to 7 (5 levels) the best k_lsi grid is half a block per CU
+  // larger.  Around that, a mild dependence on the ratio of the two sides' solo times seen in the "taking turns" trial,
+  // r = (k_lsi + its records) / (the PIP kernels).  Swept per pair with tools/share_probe.py on the round-3 kernels
+  // (profiles/r03_d_share_sweep.txt; optimum k_lsi grid at the warm r): Zipcode 0.52 -> 448-512, headline 0.53 -> 512,
+  // nested 0.72 -> 512, WaterBodies 0.77 -> 640-704, LakesNA 0.87 -> 640-704 blocks of 256 CUs' worth:
+  // 512 + 128 (8 - walk blocks per CU) + 200 (r - 0.6), within 1 % of the best step on all five; the second shared
+  // trial then tries the neighbouring grid on the side the first one's imbalance points to, and the better one stays.
+  // The PIP side (launched second) fills what is left.
   float co_ratio = 0.46f;
+  int co_wpc = 8;  // walk blocks a CU can hold for the base tree of the pair being scheduled
   int lsi_share_set = 0, pip_share_set = 0;  // "lsi_share_set" / "pip_share_set": fixed grids for schedule 1 (0 = derive them, the default)
   int co_L = 0, co_best_L = 0;  // the k_lsi grid of the next shared pair / of the best one measured (0: the formula below)
   int lsi_share_blocks() const {
     if (lsi_share_set) return lsi_share_set;
     if (co_L) return co_L;
-    const int b = ((int) ((128.0f + 736.0f * co_ratio) * (float) cus / 256.0f) + 32) / 64 * 64;
+    const int b = ((int) ((512.0f + 128.0f * (float) (8 - co_wpc) + 200.0f * (co_ratio - 0.6f)) * (float) cus / 256.0f) + 32) / 64 * 64;
     return b < cus ? cus : (b > cus * 4 ? cus * 4 : b);
   }
   int last_pip_share = 0;  // the PIP side's grid in the last shared pair (what "pip_share_blocks" reports)
@@ -136,10 +142,16 @@ struct rj_handle_s {
   uint64_t rest_cap[2] = {0, 0};
   uint32_t* todo[2] = {nullptr, nullptr};  // per stream: candidate lists the walk left to k_pip_exact, one slot per query position (grow-only)
   unsigned long long* todo_mask[2] = {nullptr, nullptr};  // ... and which slots of a group are filled
-  unsigned long long* h_rest = nullptr;    // mapped host words [2]: the rest count of the last finished query per stream (a hint
+  unsigned long long* h_rest = nullptr;    // mapped host words [0],[1]: the rest count of the last finished query per stream (a hint; [2]: see lsi_points_on_stream
   unsigned long long* d_rest = nullptr;    // for the next launch's grid and for "pip_rest"; the same memory as the device sees it)
   uint64_t walk_n[2] = {0, 0};             // size of the query the hint belongs to
   size_t count_word = 0;                   // where the latest LSI query's result count lives
+  // k_lsi_points: the pairs its gcd-free leg declines, for k_lsi_points_gcd (grow-only; counts at d_counter[12],[13], alternating)
+  uint32_t* slow_list = nullptr;
+  uint64_t slow_cap = 0;
+  int flip_slow = 0;
+  int points_split = -1;                   // "lsi_points_split": -1 by the last count (default), 0 never, 1 always
+  int last_points_split = 0;               // what the last records launch did
   unsigned long long* d_stats = nullptr;    // [16]
   unsigned long long* h_pinned = nullptr;   // [32] pinned read-back area
   // Traversal-stack fault words, [0] LSI [1] PIP: pinned host memory the kernels write directly
@@ -429,7 +441,9 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
     if (span < h->co_best[1]) h->co_best_L = used;
     const float lsi_side = a > c ? a : c;
     const float imb = (lsi_side - b) / (span > 0 ? span : 1.0f);
-    int next = ((int) ((float) used * (1.0f + 1.5f * imb)) + 16) / 32 * 32;
+    // (one 64-block step: the landscape is flat to 1-3 % per step around the best grid, and a measured neighbour is worth
+    //  more than an extrapolated one)
+    int next = used + (imb > 0 ? 64 : -64) * h->cus / 256;
     next = next < h->cus ? h->cus : (next > h->cus * 4 ? h->cus * 4 : next);
     h->co_L = next;
   }
@@ -461,6 +475,7 @@ constexpr size_t kSchedBlockWords = 8 * 128 / 8 + 16;            // one schedule
 constexpr size_t kSchedLsi = 16, kSchedPipMain = kSchedLsi + 2 * kSchedBlockWords, kSchedPipAux = kSchedPipMain + 2 * kSchedBlockWords;
 constexpr size_t kSchedWalkMain = kSchedPipAux + 2 * kSchedBlockWords, kSchedWalkAux = kSchedWalkMain + 2 * kSchedBlockWords;
 constexpr size_t kCounterBytes = (kSchedWalkAux + 2 * kSchedBlockWords) * 8;
+constexpr size_t kSlowCountWord = 12;    // [12],[13] (alternating): how many pairs k_lsi_points left to k_lsi_points_gcd
 constexpr size_t kRestCountWord = 8;     // [8],[9] main stream (alternating), [10],[11] aux: how many points k_pip_walk left to k_pip
 constexpr size_t kGridLsiCountWord = 6;  // rj_lsi_query_grid's result count (cleared by a fill: not on the hot path)
 
@@ -506,6 +521,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (ok) {
     h->h_fault[0] = h->h_fault[1] = 0;
     h->h_rest[0] = h->h_rest[1] = ~0ull;  // (no finished two-pass query yet)
+    h->h_rest[2] = ~0ull;                 // (... and no records produced yet: k_lsi_points' pair count)
     ok = hipMemset(h->d_counter, 0, kCounterBytes) == hipSuccess;
     for (size_t blk : {kSchedLsi, kSchedLsi + kSchedBlockWords, kSchedPipMain, kSchedPipMain + kSchedBlockWords, kSchedPipAux,
                        kSchedPipAux + kSchedBlockWords, kSchedWalkMain, kSchedWalkMain + kSchedBlockWords, kSchedWalkAux,
@@ -530,6 +546,7 @@ int rj_destroy(rj_handle h) {
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
   for (int k = 0; k < 2; k++) for (int i = 0; i < 2; i++) (void) hipFree(h->ordc[k][i].perm);
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
+  (void) hipFree(h->slow_list);
   (void) hipHostFree(h->h_rest); (void) hipFree(h->rest[0]); (void) hipFree(h->rest[1]); (void) hipFree(h->todo[0]); (void) hipFree(h->todo[1]); (void) hipFree(h->todo_mask[0]); (void) hipFree(h->todo_mask[1]);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
@@ -595,6 +612,15 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strncmp(name, "pip_schedule_us", 15) && name[15] >= '0' && name[15] <= '2' && !name[16])  // best span seen per schedule, microseconds (-1: not measured)
     *value = h->co_best[name[15] - '0'] < 1e29f ? (int64_t) (h->co_best[name[15] - '0'] * 1000.0f) : -1;
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
+  else if (!strcmp(name, "lsi_points_split")) *value = h->points_split;
+  else if (!strcmp(name, "lsi_points_last_split")) *value = h->last_points_split;
+  else if (!strcmp(name, "lsi_points_gcd_pairs")) {  // pairs the last two-kernel records launch left to the gcd leg (synchronises the main stream)
+    if (int r = set_device(h)) return r;
+    unsigned long long c = 0;
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    RJ_HIP(h, hipMemcpy(&c, h->d_counter + kSlowCountWord + (1 - h->flip_slow), 8, hipMemcpyDeviceToHost));
+    *value = h->last_points_split ? (int64_t) c : -1;
+  }
   else if (!strcmp(name, "pip_last_passes")) *value = h->last_passes;  // how the last PIP query ran: 3 = walk + exact + k_pip, 1 = k_pip alone
   else if (!strcmp(name, "leaf_order")) *value = h->leaf_order;
   else if (!strcmp(name, "leaf_order_used0") || !strcmp(name, "leaf_order_used1")) *value = h->bvh[name[15] - '0'].leaf_order;  // what the index of map 0 / 1 was built with
@@ -622,6 +648,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "leaf_order")) {
     if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
     h->leaf_order = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "lsi_points_split")) {
+    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "lsi_points_split: -1 by the last count, 0 never, 1 always");
+    h->points_split = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "pip_walk")) {
@@ -1010,6 +1041,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   h->lsi_inflight = async_call && qe > qb;
   h->co_measure = h->co_points = false;
   h->lsi_shared = pairable && h->co_mode == 1;
+  h->co_wpc = pip_walk_blocks_per_cu(h->bvh[base_map_id].top);
   if (h->lsi_shared && h->lsi_share_blocks() < max_blocks) max_blocks = h->lsi_share_blocks();
   tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
   if (qe > qb) {
@@ -1038,6 +1070,7 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   h->lsi_shared = h->lsi_inflight = false;
   uint64_t n = h->h_pinned[0];
+  h->h_rest[2] = n;  // (how many records a query like this one asks for: lsi_points_on_stream)
   if (h->stats_on) for (int i = 0; i < 16; i++) h->last_stats[i] = h->h_pinned[1 + i];
   if (n_found) *n_found = n;
   if (int r = check_fault(h)) return r;
@@ -1062,6 +1095,36 @@ int rj_lsi_query(rj_handle h, int base_map_id, int query_map_id, uint64_t qb, ui
   return rj_lsi_query_finish(h, capacity, n_found);
 }
 
+// The records of n pairs (or of the queue's capacity, with the count on the device) on the main stream.  Two forms:
+// k_lsi_points (gcd-free) + k_lsi_points_gcd over the pairs it declines -- 3.5x faster on 2 M pairs -- or
+// k_lsi_points_gcd alone, which is ONE latency chain instead of two: better below ~0.4 M pairs (headline pair, 0.19 M:
+// 53 us against 75 alone on the chip, and the step ends on this chain).  With the count on the device the host goes by
+// the count of the last query, which the kernels leave in mapped host memory (unknown yet: two kernels).
+constexpr uint64_t kPointsSplitAbove = 384 * 1024;
+static hipError_t lsi_points_on_stream(rj_handle h, const uint32_t* pairs_dev, uint64_t n, const unsigned long long* n_dev, XsectRec* out) {
+  const uint64_t seen = n_dev ? (uint64_t) h->h_rest[2] : n;
+  const bool split = n < (1ull << 32) && (h->points_split >= 0 ? h->points_split == 1 : (seen == ~0ull || seen >= kPointsSplitAbove));
+  if (split && h->slow_cap < n && !h->capturing) {  // (captured: whatever list there is, or the one-kernel form)
+    hipError_t e = hipStreamSynchronize(h->stream);  // (the list may be in use by records still being produced)
+    if (e != hipSuccess) return e;
+    (void) hipFree(h->slow_list);
+    h->slow_list = nullptr; h->slow_cap = 0;
+    if (hipMalloc((void**) &h->slow_list, n * 4) == hipSuccess) {
+      h->slow_cap = n;
+      (void) hipMemsetAsync(h->slow_list, 0, n * 4, h->stream);  // first touch outside the first timed use
+    } else {
+      (void) hipGetLastError();  // no room for the list: the one-kernel form below
+    }
+  }
+  uint32_t* list = split && h->slow_cap >= n ? h->slow_list : nullptr;
+  const int f = h->capturing ? 0 : h->flip_slow;
+  hipError_t e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, n_dev, out, list,
+                                   h->d_counter + kSlowCountWord + f, h->d_counter + kSlowCountWord + (1 - f), h->d_rest + 2);
+  if (list && !h->capturing) h->flip_slow = 1 - f;
+  h->last_points_split = list ? 1 : 0;
+  return e;
+}
+
 int rj_lsi_points(rj_handle h, const uint32_t* pairs_dev, uint64_t n, rj_xsect* out_dev) {
   RJ_CHECK_H(h);
   if (!h->map[0].present || !h->map[1].present) return fail(h, RJ_E_INVALID, "rj_lsi_points: both maps must be uploaded");
@@ -1069,7 +1132,7 @@ int rj_lsi_points(rj_handle h, const uint32_t* pairs_dev, uint64_t n, rj_xsect* 
   if (int r = set_device(h)) return r;
   h->co_measure = false;  // (the pair-span events are re-recorded outside a pair)
   tic(h, RJ_T_LSI_POINTS);
-  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, nullptr, (XsectRec*) out_dev));
+  RJ_HIP(h, lsi_points_on_stream(h, pairs_dev, n, nullptr, (XsectRec*) out_dev));
   toc(h, RJ_T_LSI_POINTS);
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   return RJ_OK;
@@ -1082,7 +1145,7 @@ int rj_lsi_points_async(rj_handle h, const uint32_t* pairs_dev, uint64_t capacit
   if (int r = set_device(h)) return r;
   if (h->lsi_inflight) h->co_points = true;
   tic(h, RJ_T_LSI_POINTS);
-  RJ_HIP(h, launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, capacity, h->d_counter + h->count_word, (XsectRec*) out_dev));
+  RJ_HIP(h, lsi_points_on_stream(h, pairs_dev, capacity, h->d_counter + h->count_word, (XsectRec*) out_dev));
   toc(h, RJ_T_LSI_POINTS);
   return RJ_OK;
 }
@@ -1170,7 +1233,10 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   const int walk_full = h->cus * pip_walk_blocks_per_cu(h->bvh[base_map_id].top);
   int walk_blocks = h->max_blocks;
   if (aux && h->lsi_shared) {
-    const int share = h->pip_share_set ? h->pip_share_set : walk_full - h->cus;
+    // (k_lsi on up to two blocks per CU: the walk leaves exactly that room -- 6 + 2 resident blocks per CU, nothing
+    //  waits for a slot; a larger LSI share: the walk keeps all but one, the LSI side's later blocks fill in as it drains.
+    //  tools/share_probe.py on the headline pair: 512 + 1536 blocks 0.897 ms, 512 + 1792 0.907, 448 + 1792 0.917)
+    const int share = h->pip_share_set ? h->pip_share_set : walk_full - (h->lsi_share_blocks() <= 2 * h->cus ? 2 : 1) * h->cus;
     walk_blocks = share < h->max_blocks ? share : h->max_blocks;
   }
   if (aux && h->lsi_shared) h->last_pip_share = max_blocks;  // (overwritten below when the walk runs)
@@ -1531,7 +1597,7 @@ int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint6
   hipError_t e = hipSuccess;
   do {
     // 1. the 48-byte records  2. order by (eid[im], eid[1-im])  3. per-edge order by distance, mid-points
-    if ((e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, nullptr, tmp)) != hipSuccess) break;
+    if ((e = lsi_points_on_stream(h, pairs_dev, n, nullptr, tmp)) != hipSuccess) break;
     if ((e = launch_xsect_keys(h->stream, tmp, n, im, kin, vin)) != hipSuccess) break;
     if ((e = sort_pairs_u64_u32(h->stream, temp, temp_bytes, kin, kout, vin, vout, n)) != hipSuccess) break;
     if ((e = launch_xsect_gather(h->stream, tmp, vout, n, (XsectRec*) xsects_dev)) != hipSuccess) break;
@@ -1595,6 +1661,7 @@ int rj_graph_begin(rj_handle h, int id) {
   // and clears them first (the kernels still clear set 1, which nothing reads); each stream clears what its kernels use
   if (e == hipSuccess) e = hipMemsetAsync(h->d_counter, 0, 16, h->stream);                                // LSI result counts
   if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kRestCountWord, 0, 16, h->stream);               // the main stream's rest counts
+  if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kSlowCountWord, 0, 16, h->stream);               // k_lsi_points' list counts
   for (size_t blk : {kSchedLsi, kSchedPipMain, kSchedWalkMain})
     if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + blk, 0, 8 * 128, h->stream);                   // 8 counters, 128 B apart
   if (h->cap_aux) {

@@ -120,7 +120,9 @@ hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, 
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                              uint64_t n, MortonKey* keys, uint32_t* vals);
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
-                             uint64_t n, const unsigned long long* n_dev, XsectRec* out);
+                             uint64_t n, const unsigned long long* n_dev, XsectRec* out, uint32_t* slow_list,
+                             unsigned long long* slow_count, unsigned long long* next_slow_count,
+                             unsigned long long* count_hint);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
 hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
 hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks);

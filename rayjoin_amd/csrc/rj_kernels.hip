@@ -750,19 +750,35 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
 // =============================================================================================
 // n_dev (nullable): the result count as the LSI kernel left it on the device -- the records of a
 // query are then produced on the stream with no host round trip in between (min(*n_dev, n) pairs).
-__global__ __launch_bounds__(256) void k_lsi_points(const Seg* __restrict__ seg0,
-                                                    const Seg* __restrict__ seg1,
-                                                    const uint32_t* __restrict__ pairs, uint64_t n,
-                                                    const unsigned long long* __restrict__ n_dev,
-                                                    XsectRec* __restrict__ out) {
+// Two kernels: k_lsi_points decides a pair's stored coordinates from one exact floor division per coordinate
+// (lsi_stored_fast: 98-99 % of the pairs at map-like magnitudes, every exact hit on a shared vertex among them) and
+// appends the pairs it declines -- a coordinate within |v| 2^-51 of an integer without being one -- to a list;
+// k_lsi_points_gcd, right behind it, gives those the simplified rational itself (128-bit gcd: ~20x the instructions,
+// divergent loops, 145 VGPRs) with every lane busy.  One kernel doing both held 62 lanes of nearly every wave up for
+// the one or two that needed the gcd (a wave sees too few pairs to fill a queue of its own), and kept the fast leg at
+// 3 waves per SIMD.  `slow_list` == nullptr: k_lsi_points_gcd alone over all pairs (n >= 2^32, or no list memory).
+__global__ __launch_bounds__(256) void k_lsi_points_gcd(const Seg* __restrict__ seg0, const Seg* __restrict__ seg1,
+                                                        const uint32_t* __restrict__ pairs, uint64_t n,
+                                                        const unsigned long long* __restrict__ n_dev,
+                                                        const uint32_t* __restrict__ slow_list,
+                                                        const unsigned long long* __restrict__ slow_count,
+                                                        unsigned long long* __restrict__ count_hint,
+                                                        XsectRec* __restrict__ out) {
   if (n_dev) {
     const unsigned long long found = *n_dev;
     n = found < n ? found : n;
   }
-  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n;
-       i += (uint64_t) gridDim.x * blockDim.x) {
-    uint32_t e0 = pairs[2 * i], e1 = pairs[2 * i + 1];
-    Seg s1 = seg0[e0], s2 = seg1[e1];
+  // (the host picks the one- or two-kernel form for the next query by this count: mapped host memory, a plain store)
+  if (count_hint && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(count_hint, (unsigned long long) n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint64_t m = n;
+  if (slow_list) {
+    const unsigned long long listed = *slow_count;
+    m = listed < n ? listed : n;
+  }
+  for (uint64_t j = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; j < m; j += (uint64_t) gridDim.x * blockDim.x) {
+    const uint64_t i = slow_list ? slow_list[j] : j;
+    const uint32_t e0 = pairs[2 * i], e1 = pairs[2 * i + 1];
+    const Seg s1 = seg0[e0], s2 = seg1[e1];
     Rat x, y;
     lsi_point(s1, make_eqn(s1), s2, make_eqn(s2), &x, &y);
     XsectRec r;
@@ -776,6 +792,67 @@ __global__ __launch_bounds__(256) void k_lsi_points(const Seg* __restrict__ seg0
     r.pad = 0;
     out[i] = r;
   }
+}
+
+__global__ __launch_bounds__(256) void k_lsi_points(const Seg* __restrict__ seg0,
+                                                    const Seg* __restrict__ seg1,
+                                                    const uint32_t* __restrict__ pairs, uint64_t n,
+                                                    const unsigned long long* __restrict__ n_dev,
+                                                    uint32_t* __restrict__ slow_list,
+                                                    unsigned long long* __restrict__ slow_count,
+                                                    unsigned long long* __restrict__ next_slow_count,
+                                                    unsigned long long* __restrict__ count_hint,
+                                                    XsectRec* __restrict__ out) {
+  __shared__ uint32_t slowq[4][128];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *next_slow_count = 0;  // (the next query's list; see k_lsi's counters)
+  if (n_dev) {
+    const unsigned long long found = *n_dev;
+    n = found < n ? found : n;
+  }
+  if (count_hint && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(count_hint, (unsigned long long) n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  int nq = 0;  // wave-uniform fill of this wave's queue
+  auto flush = [&](int count) {  // the first `count` entries of the queue go to the list: one atomic per flush
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(slow_count, (unsigned long long) count);
+    at = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (at >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) at);
+    if (lane < count) slow_list[at + lane] = slowq[wib][lane];
+  };
+  for (uint64_t base = ((uint64_t) blockIdx.x * 4 + wib) * 64; base < n; base += (uint64_t) gridDim.x * 256) {
+    const uint64_t i = base + lane;
+    bool declined = false;
+    if (i < n) {
+      const uint2 pr = reinterpret_cast<const uint2*>(pairs)[i];
+      const Seg s1 = seg0[pr.x], s2 = seg1[pr.y];
+      XsectRec r;
+      if (lsi_stored_fast(s1, s2, &r.x_num, &r.y_num)) {
+        r.x_den = 1;
+        r.y_den = 1;
+        r.eid0 = pr.x;
+        r.eid1 = pr.y;
+        r.mid = -1;
+        r.pad = 0;
+        out[i] = r;
+      } else {
+        declined = true;
+      }
+    }
+    const uint64_t dm = __ballot(declined);
+    if (dm) {
+      if (declined) slowq[wib][nq + rank_below(dm)] = (uint32_t) i;  // (n < 2^32 on this path)
+      nq += __popcll(dm);
+      wave_lds_fence();
+      if (nq >= 64) {
+        flush(64);
+        wave_lds_fence();
+        if (lane < nq - 64) slowq[wib][lane] = slowq[wib][64 + lane];
+        nq -= 64;
+        wave_lds_fence();
+      }
+    }
+  }
+  if (nq) flush(nq);
 }
 
 
@@ -1668,11 +1745,21 @@ hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, co
 }
 
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
-                             uint64_t n, const unsigned long long* n_dev, XsectRec* out) {
+                             uint64_t n, const unsigned long long* n_dev, XsectRec* out, uint32_t* slow_list,
+                             unsigned long long* slow_count, unsigned long long* next_slow_count, unsigned long long* count_hint) {
   if (n == 0) return hipSuccess;
   // with a device-side count the grid is sized for a typical result, the loop is grid-stride anyway
   const uint64_t expect = n_dev ? (n < (1u << 20) ? n : (1u << 20)) : n;
-  hipLaunchKernelGGL(k_lsi_points, dim3(grid_for(expect, 256, 4096)), dim3(256), 0, st, seg0, seg1, pairs, n, n_dev, out);
+  if (!slow_list || n >= (1ull << 32)) {
+    hipLaunchKernelGGL(k_lsi_points_gcd, dim3(grid_for(expect, 256, 4096)), dim3(256), 0, st, seg0, seg1, pairs, n, n_dev,
+                       (const uint32_t*) nullptr, (const unsigned long long*) nullptr, count_hint, out);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(k_lsi_points, dim3(grid_for(expect, 256, 2048)), dim3(256), 0, st, seg0, seg1, pairs, n, n_dev, slow_list,
+                     slow_count, next_slow_count, count_hint, out);
+  // (a few per cent of the pairs at most on map-like data; sized for that, grid-stride for the rest)
+  hipLaunchKernelGGL(k_lsi_points_gcd, dim3(grid_for(expect / 16 + 1, 256, 1024)), dim3(256), 0, st, seg0, seg1, pairs, n, n_dev,
+                     (const uint32_t*) slow_list, (const unsigned long long*) slow_count, (unsigned long long*) nullptr, out);
   return hipGetLastError();
 }
 

@@ -229,6 +229,86 @@ RJ_HD void lsi_point(const Seg& s1, const Eqn& e1, const Seg& s2, const Eqn& e2,
   *oy = y;
 }
 
+// ---- the narrowing store without the gcd ------------------------------------------------
+// What is stored of an intersection is (int64_t) ((double) num' / (double) den') of the SIMPLIFIED, clamped rational
+// (lsi.h:117-143, rational.h:335-343).  The gcd only matters through the rounding of num' and den': with
+// v = num / den, q = floor(v), r = num - q den (den > 0 after the sign normalisation of rational.h:198-203):
+//   * v < t_min or v > t_max (integers; v < t <=> q < t, v > t <=> q > t or q == t and r > 0): the clamp value, exactly;
+//   * r == 0: the gcd is den, the simplified rational is q / 1, the store is q;
+//   * otherwise the double quotient Q of the simplified rational is within |v| 2^-51 of v whatever the gcd was (three
+//     roundings of 2^-53 each), so when v keeps that distance from q and from q + 1 -- r and den - r both above
+//     |num| 2^-51 -- Q lies strictly between them and truncates toward zero to q (v > 0) or q + 1 (v < 0).
+// Only a coordinate that comes closer to an integer than that without being one (1-2 % of them at 2^44) needs
+// num' and den' themselves: the caller takes lsi_point for those.  No 128-bit gcd, no modular inverse, one
+// double-estimated quotient per coordinate.  false = not decided here (also: den == 0, magnitudes the short
+// quotient or the clamp's exact comparison cannot take).
+RJ_HD bool lsi_coord_fast(i128 num, i128 den, int64_t t_min, int64_t t_max, int64_t* out) {
+  if (den == 0) return false;
+  const bool flip = den < 0;
+  const u128 D = uabs128(den);
+  const i128 sn = flip ? (i128) ((u128) 0 - (u128) num) : num;
+  const u128 a = uabs128(sn);
+  if ((uint64_t) (D >> 80) != 0 || (uint64_t) (a >> 126) != 0) return false;  // (t * den' cannot wrap below 2^80)
+  uint64_t qa = 0;
+  u128 ra = a;
+  if (a >= D) {
+    const int la = 128 - clz128(a), lb = 128 - clz128(D);
+    if (la - lb > 47) return false;  // quotient < 2^48: the estimate below (relative error < 2^-50) is within 1 of it
+    const double da = (double) (uint64_t) (a >> 64) * 18446744073709551616.0 + (double) (uint64_t) a;
+    const double db = (double) (uint64_t) (D >> 64) * 18446744073709551616.0 + (double) (uint64_t) D;
+    qa = (uint64_t) (da / db);  // within 1 of floor(a / D), as in mod128
+    u128 p = (u128) qa * D;
+    if (p > a) {
+      p -= D;
+      qa--;
+    }
+    ra = a - p;
+    if (ra >= D) {
+      ra -= D;
+      qa++;
+    }
+  }
+  // floor and remainder of the signed value
+  int64_t q = (int64_t) qa;
+  u128 r = ra;
+  if (sn < 0) {
+    q = ra == 0 ? -q : -q - 1;
+    r = ra == 0 ? (u128) 0 : D - ra;
+  }
+  if (q < t_min) {
+    *out = t_min;
+    return true;
+  }
+  if (q > t_max || (q == t_max && r != 0)) {
+    *out = t_max;
+    return true;
+  }
+  if (r == 0) {
+    *out = q;
+    return true;
+  }
+  const u128 m = (a >> 51) + 1;
+  if (r < m || D - r < m) return false;
+  *out = sn < 0 ? q + 1 : q;
+  return true;
+}
+
+// both stored coordinates of a predicate-true pair, or false (then: lsi_point + rat_to_double)
+RJ_HD bool lsi_stored_fast(const Seg& s1, const Seg& s2, int64_t* ox, int64_t* oy) {
+  // den, nx, ny of lsi.h:117-119 with the 64-bit a, b of map.h:216-226 kept 64-bit (the same values modulo 2^128,
+  // a quarter of the multiplications of the all-128-bit form)
+  int64_t a1 = s1.y1 - s1.y2, b1 = s1.x2 - s1.x1, a2 = s2.y1 - s2.y2, b2 = s2.x2 - s2.x1;
+  u128 c1 = (u128) 0 - (u128) ((i128) s1.x1 * a1) - (u128) ((i128) s1.y1 * b1);
+  u128 c2 = (u128) 0 - (u128) ((i128) s2.x1 * a2) - (u128) ((i128) s2.y1 * b2);
+  if (b1 < 0) { a1 = -a1; b1 = -b1; c1 = (u128) 0 - c1; }
+  if (b2 < 0) { a2 = -a2; b2 = -b2; c2 = (u128) 0 - c2; }
+  const i128 den = (i128) a1 * b2 - (i128) a2 * b1;
+  const i128 nx = (i128) (c2 * (u128) (i128) b1 - c1 * (u128) (i128) b2);
+  const i128 ny = (i128) ((u128) (i128) a2 * c1 - (u128) (i128) a1 * c2);
+  return lsi_coord_fast(nx, den, min4(s1.x1, s1.x2, s2.x1, s2.x2), max4(s1.x1, s1.x2, s2.x1, s2.x2), ox) &&
+         lsi_coord_fast(ny, den, min4(s1.y1, s1.y2, s2.y1, s2.y2), max4(s1.y1, s1.y2, s2.y1, s2.y2), oy);
+}
+
 // ---- PIP ------------------------------------------------------------------------------
 // (double) of a 128-bit integer, round-to-nearest-even like the compiler's conversion (what the
 // reference's `(double) int128` is), but through the top 64 bits + a sticky bit instead of the

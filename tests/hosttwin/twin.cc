@@ -23,6 +23,41 @@ void twin_lsi_stored(const int64_t* s1, const int64_t* s2, int64_t* out) {
   out[1] = (int64_t) rat_to_double(y);
 }
 
+// the gcd-free store: returns 1 and fills out[0..1] when it decides, 0 when the caller must take twin_lsi_stored
+int twin_lsi_stored_fast(const int64_t* s1, const int64_t* s2, int64_t* out) {
+  const Seg a = {s1[0], s1[1], s1[2], s1[3]}, b = {s2[0], s2[1], s2[2], s2[3]};
+  return lsi_stored_fast(a, b, &out[0], &out[1]) ? 1 : 0;
+}
+
+// one coordinate: (num, den) as 128-bit halves, clamp range -> 1 and *fast when decided; *slow = what
+// rat_make + the clamp of lsi.h:121-141 + the narrowing store give
+int twin_lsi_coord(int64_t nh, uint64_t nl, int64_t dh, uint64_t dl, int64_t t_min, int64_t t_max, int64_t* fast, int64_t* slow) {
+  const i128 num = (i128) (((u128) (uint64_t) nh << 64) | nl), den = (i128) (((u128) (uint64_t) dh << 64) | dl);
+  Rat x = rat_make(num, den);
+  if (x.num < (i128) ((u128) (i128) t_min * (u128) x.den)) { x.num = t_min; x.den = 1; }
+  if ((i128) ((u128) (i128) t_max * (u128) x.den) < x.num) { x.num = t_max; x.den = 1; }
+  *slow = (int64_t) rat_to_double(x);
+  return lsi_coord_fast(num, den, t_min, t_max, fast) ? 1 : 0;
+}
+
+// bulk form for the fuzz test: n pairs of segments (8 int64 each); counts[0] = predicate-true pairs,
+// counts[1] = decided by the fast path, counts[2] = decided differently from the slow path (must stay 0)
+void twin_lsi_stored_fuzz(const int64_t* segs, uint64_t n, uint64_t* counts) {
+  counts[0] = counts[1] = counts[2] = 0;
+  for (uint64_t k = 0; k < n; k++) {
+    const int64_t* s = segs + 8 * k;
+    const Seg a = {s[0], s[1], s[2], s[3]}, b = {s[4], s[5], s[6], s[7]};
+    if (!lsi_test(a, b)) continue;
+    counts[0]++;
+    int64_t fx, fy;
+    if (!lsi_stored_fast(a, b, &fx, &fy)) continue;
+    counts[1]++;
+    Rat x, y;
+    lsi_point(a, make_eqn(a), b, make_eqn(b), &x, &y);
+    if (fx != (int64_t) rat_to_double(x) || fy != (int64_t) rat_to_double(y)) counts[2]++;
+  }
+}
+
 // returns 1 when the edge is a candidate; *yy = xsect_y, *slope = (double) a / (double) b
 int twin_pip_eval(const int64_t* s, int64_t px, int64_t py, int query_map_id, double* yy, double* slope) {
   const Seg e = {s[0], s[1], s[2], s[3]};

@@ -29,6 +29,9 @@ def twin():
     L.twin_pip_eval.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.twin_i128_to_double.argtypes = [C.c_int64, C.c_uint64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.twin_rat_make.argtypes = [C.c_int64, C.c_uint64, C.c_int64, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.twin_lsi_stored_fast.argtypes = [i64p, i64p, i64p]
+    L.twin_lsi_coord.argtypes = [C.c_int64, C.c_uint64, C.c_int64, C.c_uint64, C.c_int64, C.c_int64, i64p, i64p]
+    L.twin_lsi_stored_fuzz.argtypes = [i64p, C.c_uint64, C.POINTER(C.c_uint64)]
     L.twin_pip_better.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_double, C.c_double, C.c_uint32, C.c_int]
     return L
 
@@ -147,3 +150,75 @@ def test_rational_simplify_is_exact(twin):
         gn, gd = (out[0] << 64) | out[1], (out[2] << 64) | out[3]
         gn = gn - M if gn >= 1 << 127 else gn
         assert (gn, gd) == (wn, wd), (n, d)
+
+
+def _halves(v):
+    w = v % (1 << 128)
+    hi = w >> 64
+    return (hi - (1 << 64) if hi >= 1 << 63 else hi), w & ((1 << 64) - 1)
+
+
+def test_gcd_free_store_one_coordinate(twin):
+    """lsi_coord_fast against rat_make + clamp + (int64_t) double quotient on constructed rationals num / den =
+    q + r / D: remainders at and next to 0 and D (where the rounded quotient of the simplified rational can land on the
+    neighbouring integer -- the fast path must then either decline or agree), common factors of every size (the gcd
+    changes what is rounded), both signs of num and den, clamps that cut below, above and exactly at q."""
+    import random
+    rng = random.Random(33)
+    fast, slow = np.zeros(1, dtype=np.int64), np.zeros(1, dtype=np.int64)
+    decided = declined = 0
+    for it in range(40000):
+        db = rng.randrange(1, 80)
+        D = rng.randrange(1 << (db - 1), 1 << db)
+        qb = rng.randrange(0, 47)
+        q = rng.randrange(-(1 << qb), (1 << qb) + 1)
+        kind = it % 8
+        if kind == 0:
+            r = 0
+        elif kind == 1:
+            r = min(D - 1, rng.randrange(0, 4))
+        elif kind == 2:
+            r = max(0, D - 1 - rng.randrange(0, 4))
+        elif kind == 3:  # right at the declared margin |num| 2^-51
+            r = min(D - 1, max(0, ((abs(q) * D) >> 51) + rng.randrange(-2, 3)))
+        elif kind == 4:
+            r = max(0, D - 1 - max(0, ((abs(q) * D) >> 51) + rng.randrange(-2, 3)))
+        else:
+            r = rng.randrange(0, D)
+        g = 1 if it % 3 == 0 else rng.randrange(1, 1 << rng.randrange(1, 40))
+        num, den = (q * D + r) * g, D * g
+        if abs(num) >= 1 << 126 or den >= 1 << 126:
+            continue
+        if rng.randrange(0, 2):
+            num, den = -num, -den
+        lo = q - rng.randrange(0, 3) if it % 5 else q + 1 + rng.randrange(0, 5)
+        hi = max(lo, q + rng.randrange(0, 3) if it % 7 else q - 1 - rng.randrange(0, 5))
+        ok = twin.twin_lsi_coord(*_halves(num), *_halves(den), lo, hi, _p(fast), _p(slow))
+        if ok:
+            decided += 1
+            assert fast[0] == slow[0], (num, den, lo, hi, int(fast[0]), int(slow[0]))
+        else:
+            declined += 1
+    assert decided > 25000 and declined > 500  # both legs exercised
+
+
+@pytest.mark.parametrize("center_bits,box_bits", [(0, 3), (0, 12), (44, 6), (44, 20), (44, 30), (46, 10), (30, 30)])
+def test_gcd_free_store_on_crossing_segments(twin, center_bits, box_bits):
+    """lsi_stored_fast against lsi_point + the narrowing store on random predicate-true pairs: lattice-sized boxes (exact
+    hits on vertices and T-junctions: r == 0), map-like magnitudes (2^44 with edges of 2^6 .. 2^30), the 2^46 corner."""
+    rng = np.random.default_rng(center_bits * 100 + box_bits)
+    n = 400000
+    c = rng.integers(-(1 << center_bits), (1 << center_bits) + 1, size=(n, 1, 2), dtype=np.int64) if center_bits else np.zeros((n, 1, 2), dtype=np.int64)
+    if center_bits == 46:
+        c = np.sign(c) * ((1 << 46) - (1 << box_bits) - 2)
+    segs = (c + rng.integers(-(1 << box_bits), (1 << box_bits) + 1, size=(n, 4, 2), dtype=np.int64)).reshape(n, 8)
+    ok = ((segs[:, 0] != segs[:, 2]) | (segs[:, 1] != segs[:, 3])) & ((segs[:, 4] != segs[:, 6]) | (segs[:, 5] != segs[:, 7]))
+    segs = np.ascontiguousarray(segs[ok])
+    counts = (C.c_uint64 * 3)()
+    twin.twin_lsi_stored_fuzz(_p(segs), len(segs), counts)
+    hits, fast, wrong = counts[0], counts[1], counts[2]
+    assert hits > 20000 and wrong == 0
+    print("center 2^%d box 2^%d: %d hits, %.2f %% decided without the gcd" % (center_bits, box_bits, hits, 100.0 * fast / hits))
+    # the point of it: the gcd is the exception (the margin is |v| 2^-51 on either side of an integer: 2 x 2^-5 per
+    # coordinate at the 2^46 corner, 2 x 2^-7 at 2^44)
+    assert fast > (0.85 if center_bits == 46 else 0.95) * hits, (hits, fast)

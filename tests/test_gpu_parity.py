@@ -528,3 +528,49 @@ def test_captured_step_replays_the_same_results(oracle):
             h.graph_launch(3)  # never captured
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_records_by_either_form_equal_the_oracle(oracle, split):
+    """rj_lsi_points: k_lsi_points_gcd alone ("lsi_points_split" 0) and k_lsi_points + k_lsi_points_gcd over the pairs
+    the gcd-free leg declines (1) leave the same 48-byte records as the oracle -- on a nested pair at map magnitudes
+    (coordinates ~2^44: exact hits on shared vertices AND coordinates within 2^-7 of an integer, so the two-kernel form
+    uses both of its legs), on the small integer lattice and in the +-2^46 corner."""
+    cases = [("nested", maps.Context([synth.standin("USCounty", 0.04), synth.standin("NestedBlockGroup", 0.04)]).load())]
+    for name, extreme in (("lattice", False), ("corner", True)):
+        c = maps.Context([None, None])
+        c.maps = [maps.ScaledMap.from_segments(0, synth.adversarial_segments(300, 7, 3, extreme)),
+                  maps.ScaledMap.from_segments(1, synth.adversarial_segments(300, 7, 4, extreme))]
+        cases.append((name, c))
+    for name, ctx in cases:
+        dctx = ops.DeviceContext(ctx).LoadToDevice()
+        dctx.BuildIndex(0)
+        h = dctx.handle
+        h.set_option("lsi_points_split", split)
+        m0, m1 = _omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1])
+        want = oracle.lsi_brute(m0, m1)
+        cap = len(want) + 64
+        pairs, recs = h.alloc(8 * cap), h.alloc(48 * cap)
+        n = h.lsi_query(0, 1, 0, ctx.maps[1].n_edges, cap, pairs)
+        assert n == len(want) and n > 100, name
+        h.lsi_points(pairs, n, recs)
+        assert h.get_option("lsi_points_last_split") == split
+        got = recs.to_host(_capi.XSECT_DTYPE, n)
+        ref = oracle.lsi_points(m0, m1, np.ascontiguousarray(got["eid"]))
+        for f in ("x_num", "x_den", "y_num", "y_den"):
+            assert np.array_equal(got[f], ref[f]), (name, f)
+        if split:
+            left = h.get_option("lsi_points_gcd_pairs")
+            assert 0 <= left < n
+            if name == "nested":
+                assert 0 < left < n // 8, (left, n)  # both legs worked, the gcd is the exception
+            if name == "lattice":
+                assert left == 0  # every product exact, every quotient far from the next integer or ON it
+        # ... and behind an asynchronous query, the count read on the device
+        h.lsi_query_async(0, 1, 0, ctx.maps[1].n_edges, cap, pairs)
+        h.lsi_points_async(pairs, cap, recs)
+        assert h.lsi_query_finish(cap) == n
+        got2 = recs.to_host(_capi.XSECT_DTYPE, n)
+        ref2 = oracle.lsi_points(m0, m1, np.ascontiguousarray(got2["eid"]))
+        assert np.array_equal(got2["x_num"], ref2["x_num"]) and np.array_equal(got2["y_num"], ref2["y_num"]), name
+        dctx.close()
