@@ -1295,25 +1295,28 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
     toc(h, RJ_T_PIP_WALK, st);
     if (!h->capturing) h->flip_walk[si] = 1 - wflip;
-    RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8));
-    // second pass over what is left: the grid follows the last count seen for this query size
-    a.order = h->rest[si];
-    a.n_dev = w.rest_count;
-    a.rest_count = h->d_rest + si;  // (k_pip reports the count it found to the host)
+    // second pass: the exact predicate over the candidate lists, and -- the kernel's first blocks -- k_pip's traversal
+    // over the points whose list overflowed; that part's grid follows the last count seen for this query size
     // (the list is appended group by group all over the map: the fewer points it holds, the less a wave's points have
     //  to do with each other -- a handful of overflowed lists are unrelated traversals, one wave each)
     const uint64_t left = seen != ~0ull ? seen : 8192;
-    a.group_lanes = left < 8192 ? 1 : (left * 100 < n ? 4 : (left * 10 < n ? 8 : 16));
-    a.chunk_groups = 1;
-    a.stats = nullptr;
-    int rest_blocks = max_blocks;
+    PipRestArgs r;
+    r.order = h->rest[si];
+    r.n_dev = w.rest_count;
+    r.rest_count = h->d_rest + si;  // (the count goes to the host)
+    r.work_counter = a.work_counter;
+    r.next_work_counter = a.next_work_counter;
+    r.group_lanes = left < 8192 ? 1 : (left * 100 < n ? 4 : (left * 10 < n ? 8 : 16));
+    r.chunk_groups = 1;
+    int rest_blocks = h->cus * 4;
     if (seen != ~0ull) {
-      const uint64_t want = seen / (a.group_lanes * 4 * 2) + 1;  // about two groups per wave
-      const uint64_t floor_blocks = (uint64_t) h->cus;
-      rest_blocks = (int) (want < floor_blocks ? floor_blocks : (want > (uint64_t) max_blocks ? (uint64_t) max_blocks : want));
+      const uint64_t want = seen / (r.group_lanes * 4 * 2) + 1;  // about two groups per wave
+      const uint64_t lo = (uint64_t) h->cus / 4, hi = (uint64_t) h->cus * 4;  // (at least a block per four CUs: the count is a hint)
+      rest_blocks = (int) (want < lo ? lo : (want > hi ? hi : want));
     }
+    r.blocks = (uint32_t) rest_blocks;
     h->walk_n[si] = n;
-    RJ_HIP(h, launch_pip(st, a, false, rest_blocks));
+    RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8, r));
     if (!h->capturing) h->flip_pip[si] = 1 - pflip;
   } else if (n) {
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));

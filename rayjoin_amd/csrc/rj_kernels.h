@@ -12,6 +12,18 @@ struct XsectRec {  // == rj_xsect (include/rayjoin_amd.h) == dev::Intersection<i
 static_assert(sizeof(XsectRec) == 48, "Intersection record must be 48 bytes");
 static_assert(sizeof(Seg) == 32 && sizeof(QBox) == 16, "layout");
 
+// what the first `blocks` blocks of k_pip_exact need to run k_pip's traversal over the walk's overflowed lists
+// (everything else is the PipArgs of the launch)
+struct PipRestArgs {
+  const uint32_t* order;                 // the walk's rest list
+  const unsigned long long* n_dev;       // ... and its count, on the device
+  unsigned long long* rest_count;        // mapped host word: the count, for the next launch's grid
+  unsigned int* work_counter;            // a scheduler block of its own (the exact blocks use none)
+  unsigned int* next_work_counter;
+  uint32_t group_lanes, chunk_groups;
+  uint32_t blocks;                       // 0: none (the kernel is k_pip_exact proper)
+};
+
 struct LsiArgs {
   DeviceBvh bvh;
   const Seg* qseg;     // query map segments in eid order
@@ -125,7 +137,7 @@ hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, c
                              unsigned long long* count_hint);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
 hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
-hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks);
+hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks, const PipRestArgs& r);
 int pip_walk_list_slots();  // candidates a todo record holds
 uint32_t pip_walk_group_lanes(uint64_t n, int top, int cus);  // points per wave k_pip_walk uses when the caller leaves it open
 int pip_walk_blocks_per_cu(int top);  // resident 256-thread blocks of k_pip_walk per compute unit for a tree of this height

@@ -962,20 +962,23 @@ struct PipWaveLds {
   uint32_t cand[kPipList][64];
 };
 
+// (a device function: k_pip runs it on every block, k_pip_exact on its first few -- the overflowed lists of the walk)
 template <bool STATS>
-__global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
+__device__ __forceinline__ void pip_locate(const PipArgs& A, const uint32_t bid, const PipRestArgs& Q, unsigned long long* const stats) {
+  // (Q: the query set and the scheduler block -- k_pip passes its own arguments' -- so that k_pip_exact's first blocks
+  //  need no private copy of the arguments: the tree's level arrays are indexed dynamically and would live in scratch)
   __shared__ PipWaveLds lds[kPipWaves];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   PipWaveLds& L = lds[wib];
-  const uint32_t GL = A.group_lanes;  // points per wave: 64, or fewer for small query sets
+  const uint32_t GL = Q.group_lanes;  // points per wave: 64, or fewer for small query sets
   // (behind k_pip_walk: the queries are the points it left over, counted on the device)
   uint64_t nq = A.n;
-  if (A.n_dev) {
-    const unsigned long long left = __hip_atomic_load(A.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (Q.n_dev) {
+    const unsigned long long left = __hip_atomic_load(Q.n_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nq = left < nq ? left : nq;
     // (the host sizes the next launch's grid by this count: mapped host memory, a plain store)
-    if (A.rest_count && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(A.rest_count, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (Q.rest_count && bid == 0 && threadIdx.x == 0) __hip_atomic_store(Q.rest_count, left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
@@ -986,23 +989,23 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
   long long tk_drain = 0, tk_leaf = 0, tk_node = 0, tk_rounds = 0, tk_sched = 0, tk_head = 0, tk_tail = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
-  const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
-  int part = blockIdx.x & 7, tried = 0;
+  const uint32_t nchunks = (uint32_t) ((ngroups + Q.chunk_groups - 1) / Q.chunk_groups);
+  int part = bid & 7, tried = 0;
   __shared__ unsigned long long ranges[kPipWaves];  // per wave {end : next}: the unstarted rest of its chunk
   if (threadIdx.x < kPipWaves) ranges[threadIdx.x] = 0;
-  if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;  // (see k_lsi; any block size has these threads)
+  if (bid == 0 && threadIdx.x < 8) Q.next_work_counter[threadIdx.x * 32] = 0;  // (see k_lsi; any block size has these threads)
   __syncthreads();
   for (;;) {  // XCD-aware dynamic chunked scheduling, see next_chunk / next_group
   {
     uint32_t g32 = 0;
     const long long tks = STATS ? clock64() : 0;
-    if (!next_group<kPipWaves>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
+    if (!next_group<kPipWaves>(ranges, wib, Q.work_counter, nchunks, Q.chunk_groups, ngroups, part, tried, lane, g32)) break;
     if (STATS) tk_sched += clock64() - tks;
     const uint64_t g = g32;
     const long long tkg = STATS ? clock64() : 0;
     const uint64_t ipos = g * GL + lane;  // position in the (possibly Morton-sorted) query order
     const bool valid = (uint32_t) lane < GL && ipos < nq;
-    const uint64_t ip = A.order ? (valid ? A.order[ipos] : 0) : ipos;
+    const uint64_t ip = Q.order ? (valid ? Q.order[ipos] : 0) : ipos;
     // The traversal works on the quantised point; the exact coordinates are read again (an L2 hit)
     // by the few lanes whose candidates need the exact arithmetic -- 0.2 per group on the headline
     // workload -- instead of occupying four of the kernel's 80 registers throughout.
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
       QBox b = T.lvl[T.top][lane];
       const uint64_t higher = sibling_order(T, T.top)[lane];  // (requested with the box: one latency, not two)
       uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
-      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+      if (!stack_has_room(0, __popcll(m), stack_cap, Q.work_counter, kFaultPipStack, lane)) m = 0;
       const int n = __popcll(m);
       const int at = __popcll(m & higher);
       if ((m >> lane) & 1)
@@ -1124,7 +1127,7 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
         QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
         const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane];  // (both loads in flight together)
         uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
-        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+        if (!stack_has_room(sp, __popcll(m), stack_cap, Q.work_counter, kFaultPipStack, lane)) m = 0;
         const int n = __popcll(m);
         const int at = __popcll(m & higher);
         if ((m >> lane) & 1)
@@ -1208,25 +1211,34 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
     if (STATS) tk_tail += clock64() - tkt;
   }
   }
-  if (STATS && lane == 0 && A.stats) {
+  if (STATS && lane == 0 && stats) {
     const long long tk_total = clock64() - tk_begin;
-    atomicAdd(&A.stats[0], st_leaf);
-    atomicAdd(&A.stats[1], st_tests);
-    atomicAdd(&A.stats[2], st_nodes);
-    atomicAdd(&A.stats[3], st_box);
-    atomicAdd(&A.stats[4], (unsigned long long) tk_total);
-    atomicAdd(&A.stats[5], (unsigned long long) tk_node);
-    atomicAdd(&A.stats[6], (unsigned long long) tk_leaf);
-    atomicAdd(&A.stats[7], (unsigned long long) tk_drain);
-    atomicAdd(&A.stats[8], (unsigned long long) tk_rounds);
-    atomicMax(&A.stats[9], (unsigned long long) tk_total);
-    atomicAdd(&A.stats[10], (unsigned long long) tk_sched);
-    atomicAdd(&A.stats[11], (unsigned long long) tk_head);
-    atomicAdd(&A.stats[12], (unsigned long long) tk_tail);
-    atomicAdd(&A.stats[13], st_stale);
-    atomicAdd(&A.stats[14], st_leaf_nocand);
-    atomicAdd(&A.stats[15], st_leaf_lanes);
+    atomicAdd(&stats[0], st_leaf);
+    atomicAdd(&stats[1], st_tests);
+    atomicAdd(&stats[2], st_nodes);
+    atomicAdd(&stats[3], st_box);
+    atomicAdd(&stats[4], (unsigned long long) tk_total);
+    atomicAdd(&stats[5], (unsigned long long) tk_node);
+    atomicAdd(&stats[6], (unsigned long long) tk_leaf);
+    atomicAdd(&stats[7], (unsigned long long) tk_drain);
+    atomicAdd(&stats[8], (unsigned long long) tk_rounds);
+    atomicMax(&stats[9], (unsigned long long) tk_total);
+    atomicAdd(&stats[10], (unsigned long long) tk_sched);
+    atomicAdd(&stats[11], (unsigned long long) tk_head);
+    atomicAdd(&stats[12], (unsigned long long) tk_tail);
+    atomicAdd(&stats[13], st_stale);
+    atomicAdd(&stats[14], st_leaf_nocand);
+    atomicAdd(&stats[15], st_leaf_lanes);
   }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
+  PipRestArgs Q;
+  Q.order = A.order; Q.n_dev = A.n_dev; Q.rest_count = A.rest_count;
+  Q.work_counter = A.work_counter; Q.next_work_counter = A.next_work_counter;
+  Q.group_lanes = A.group_lanes; Q.chunk_groups = A.chunk_groups; Q.blocks = 0;
+  pip_locate<STATS>(A, blockIdx.x, Q, A.stats);
 }
 
 
@@ -1500,14 +1512,23 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 #ifndef RJ_EXACT_WAVES
 #define RJ_EXACT_WAVES 5
 #endif
-__global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A) {
+// The kernel's first R.blocks blocks do something else: they locate the points whose list overflowed (the walk's `rest`
+// list, a handful to a few thousand) from scratch with k_pip's traversal.  That used to be a launch of its own behind
+// this kernel -- 30-75 us of cold, unrelated traversals, one wave each, at the very end of the step; as the first
+// blocks of this launch they start with it and end inside it.
+static_assert(kPipWaves == 4, "k_pip_exact's first blocks run pip_locate: same block size");
+__global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A, PipRestArgs R) {
+  if (blockIdx.x < R.blocks) {
+    pip_locate<false>(A, blockIdx.x, R, nullptr);
+    return;
+  }
   __shared__ uint32_t queue[4][128];
   const DeviceBvh& T = A.bvh;
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const uint32_t gl_shift = 31 - __builtin_clz(A.group_lanes);  // (group_lanes is a power of two)
-  const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6;
-  const uint64_t nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+  const uint64_t wave = ((blockIdx.x - R.blocks) * (uint64_t) blockDim.x + threadIdx.x) >> 6;
+  const uint64_t nwaves = ((uint64_t) (gridDim.x - R.blocks) * blockDim.x) >> 6;
   auto evaluate = [&](uint32_t i) {
     const uint64_t ip = A.order ? A.order[i] : i;
     uint32_t slot[kWalkList];
@@ -1791,8 +1812,8 @@ hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int 
   return hipGetLastError();
 }
 
-hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks) {
-  hipLaunchKernelGGL(k_pip_exact, dim3(blocks < 1 ? 1 : blocks), dim3(256), 0, st, a);
+hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks, const PipRestArgs& r) {
+  hipLaunchKernelGGL(k_pip_exact, dim3((blocks < 1 ? 1 : blocks) + r.blocks), dim3(256), 0, st, a, r);
   return hipGetLastError();
 }
 
