@@ -230,6 +230,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             marks.append(time.perf_counter())
         barrier()
         el = time.perf_counter() - t0
+        state["step_ms"] = [(b - a) * 1e3 for a, b in zip([t0] + marks, marks)]  # (this rank's host clock per step)
         if DEBUG_PHASES and rank == 0 and phases:
             ph = np.array(phases[-k:]) * 1e3
             print("host phases, mean ms from step begin: enqueued %.3f, main stream done %.3f, all done %.3f, timers read %.3f"
@@ -258,6 +259,10 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     settled = args.serial_kernels or never_paired or h.get_option("pip_schedule") >= 0
     elapsed = timed(steps)
     ms_per_step = elapsed * 1e3 / steps
+    # (the line's value is the K steps over their total time, as the contract says; the median and the slowest step say
+    #  whether one stall -- another tenant of the host, a driver hiccup: seen as one 11-43 ms step among 2.8 ms ones --
+    #  is in that total)
+    step_median_ms, step_max_ms = float(np.median(state["step_ms"])), float(np.max(state["step_ms"]))
     # ("auto" may have dropped the first PIP pass for this workload: then k_pip is the PIP query)
     state["two_pass"] = state["two_pass"] and h.get_option("pip_last_passes") == 3
     lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms)); walk_k = float(np.mean(walk_ms)) if (walk_ms and state["two_pass"]) else None
@@ -428,6 +433,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             "roofline_step": {"bound": "hbm", "achieved": round(b_step / (ms_per_step * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(b_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_step},
         }
+        out["ms_per_step_median"] = round(step_median_ms, 4)
+        out["ms_slowest_step"] = round(step_max_ms, 4)
         if ms_pairs_only is not None:
             out["ms_per_step_pairs_only"] = round(ms_pairs_only, 4)
             out["pip_gather_verified"] = gathered_ok
@@ -470,7 +477,7 @@ def main():
         for b, q in SECONDARY:
             torch.cuda.empty_cache()
             line = run_workload(args, env, b, q, max(5, min(args.steps, 10)), max(5, args.warmup), False, with_cpu)
-            sec.append({k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "intersections",
+            sec.append({k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_slowest_step", "config", "intersections",
                                              "build_index_ms", "lsi_points_ms", "roofline", "roofline_other", "roofline_step",
                                              "cpu_baseline") if k in line})
         out["secondary"] = sec

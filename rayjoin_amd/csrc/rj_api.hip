@@ -503,6 +503,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (!h) return RJ_E_NOMEM;
   h->device = device_id;
   if (const char* e = getenv("RJ_LEAF_ORDER")) h->leaf_order = atoi(e) == 0 ? 0 : 1;
+  if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
