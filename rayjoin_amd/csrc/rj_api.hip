@@ -1018,7 +1018,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi + flip * kSchedBlockWords);
   a.next_counter = h->d_counter + (1 - flip);
   a.next_work_counter = (unsigned int*) (h->d_counter + kSchedLsi + (1 - flip) * kSchedBlockWords);
-  a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 8);
+  a.chunk_groups = (uint32_t) h->chunk_groups;  // (0: the launch wrapper picks it by the size of the query set)
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;
@@ -1224,7 +1224,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.closest = closest_eid_dev; a.face = face_id_dev;
   a.work_counter = (unsigned int*) sched;
   a.next_work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedPipAux : kSchedPipMain) + (1 - pflip) * kSchedBlockWords);
-  a.chunk_groups = (uint32_t) (h->chunk_groups ? h->chunk_groups : 6);
+  a.chunk_groups = (uint32_t) h->chunk_groups;  // (0: the launch wrappers pick it by the size of the query set)
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
   a.stats = h->stats_on ? h->d_stats : nullptr;

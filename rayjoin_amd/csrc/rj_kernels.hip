@@ -1719,6 +1719,12 @@ static uint32_t pick_group_lanes(uint64_t nqueries, int resident_blocks_, int bl
   return gl;
 }
 
+// Consecutive groups handed to a wave at a time: k_lsi 8, the PIP kernels 6 (measured optima; a chunk's groups share
+// their tree nodes in the caches and, in the PIP kernels, a block's waves share a chunk's rest).  Smaller chunks for small
+// query sets -- so that the last chunk handed out is a smaller part of a wave's work -- were tried on the 1/8 shard of
+// the headline pair (9 groups per walk wave): 1 group per chunk, walk 169 -> 232 us.
+static uint32_t pick_chunk_groups(uint32_t requested, uint32_t optimum) { return requested ? requested : optimum; }
+
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_blocks) {
   LsiArgs a = a_in;
   const void* k = stats ? (const void*) k_lsi<true> : (const void*) k_lsi<false>;
@@ -1726,6 +1732,7 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
   if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
   if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.qend - a.qbeg, res[stats]);
   uint64_t ngroups = (a.qend - a.qbeg + a.group_lanes - 1) / a.group_lanes;
+  a.chunk_groups = pick_chunk_groups(a.chunk_groups, 8);
   uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   int grid = grid_for(nchunks, 4, res[stats] < max_blocks ? res[stats] : max_blocks);
   // A small query set (a shard of an 8-GPU run) is faster on FEWER resident waves: with under ~20
@@ -1797,12 +1804,16 @@ uint32_t pip_walk_group_lanes(uint64_t n, int top, int cus) { return pick_group_
 hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int max_blocks) {
   PipArgs a = a_in;
   const size_t lds = 4 * walk_wave_lds(a.bvh.top);
-  int dev = 0, cus = 256;
-  hipDeviceProp_t prop;
-  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  static int cus = 0;  // (asked once: the query is not free, and this sits in every step)
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
   const int res = cus * pip_walk_blocks_per_cu(a.bvh.top);
   if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.n, res, 4);
   const uint64_t ngroups = (a.n + a.group_lanes - 1) / a.group_lanes;
+  a.chunk_groups = pick_chunk_groups(a.chunk_groups, 6);
   const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
   if (stats)
@@ -1824,6 +1835,7 @@ hipError_t launch_pip(hipStream_t st, const PipArgs& a_in, bool stats, int max_b
   if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20, 64 * kPipWaves);
   if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.n, res[stats], kPipWaves);
   uint64_t ngroups = (a.n + a.group_lanes - 1) / a.group_lanes;
+  a.chunk_groups = pick_chunk_groups(a.chunk_groups, 6);
   uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   int grid = grid_for(nchunks, kPipWaves, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
