@@ -5,7 +5,7 @@ A step = one LSI Query (all query-map segments against the indexed base map: que
 traversal + predicate kernel, the 48-byte Intersection record of every hit, count read-back, sync
 -- what the reference times, src/run_query.cu:297-303 around src/app/lsi_lbvh.h:27-98)
 and one PIP Query (every vertex of the query map, src/run_query.cu:346,441-457: k_pip_walk, then
-k_pip_exact over the candidate lists it left, then k_pip over the few overflowed ones).
+k_pip_exact over the candidate lists it left; its first blocks locate the few points whose list overflowed).
 Workload (N=1): BASELINE.json configs[1], USCounty (base, 7.1 M segments) |><| BlockGroup
 (query, 28.8 M segments), as synthetic stand-ins of those sizes (the real files are
 not obtainable).  Inputs are resident in HBM before the timed region.  Index build is timed
@@ -191,7 +191,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         t_main = time.perf_counter()
         h.sync()  # joins the PIP kernels, which run on the handle's second stream beside the LSI kernel
         t_all = time.perf_counter()
-        if record:  # (one call for all stages: this sits between two steps)
+        if record and (state["k"] % 4 == 0 or not lsi_ms):  # (one call for all stages, every fourth step: it sits between two steps)
             ms = h.last_ms_all()
             if DEBUG_PHASES and world == 1:
                 phases.append((t_begin, t_enq, t_main, t_all, time.perf_counter()))
@@ -419,7 +419,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                                            -1: "k_lsi, then the PIP kernels (re-ordered query sets are never paired)" if never_paired
                                                else "undecided (fewer than 5 paired steps)"}[schedule],
                        "schedule_settled_before_timing": bool(settled),
-                       "pip_passes": ("k_pip_walk + k_pip_exact + k_pip over %s overflowed lists" % pip_rest) if state["two_pass"]
+                       "pip_passes": ("k_pip_walk + k_pip_exact (its first blocks locate the %s points whose candidate list overflowed)" % pip_rest) if state["two_pass"]
                                      else "k_pip alone" + (" (the walk left %s lists to it: auto dropped the first pass)" % pip_rest if h.get_option("pip_walk") else "")},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,

@@ -419,6 +419,7 @@ static void co_reset(rj_handle h) {
 static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
   if (!h->co_measure) return;
   h->co_measure = false;
+  if (h->co_choice >= 0) return;  // settled: nothing left to learn, and this sits in front of every step's first launch
   if (hipEventQuery(h->ev[RJ_T_LSI_KERNEL][1]) != hipSuccess || hipEventQuery(h->ev[RJ_T_PIP_KERNEL][1]) != hipSuccess) return;
   float a = 0, b = 0;
   if (hipEventElapsedTime(&a, h->ev[RJ_T_LSI_KERNEL][0], h->ev[RJ_T_LSI_KERNEL][1]) != hipSuccess) return;
@@ -438,7 +439,8 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
     // pair of a workload -- so the second shared trial corrects it by what the first one showed: the side that ended
     // later gets more of the chip.
     const int used = h->lsi_share_blocks();
-    if (span < h->co_best[1]) h->co_best_L = used;
+    // (the neighbour has to win by more than the noise of one sample, 1.5 %: near a tie the grid the sweep's fit gives stays)
+    if (h->co_best_L == 0 || span < h->co_best[1] * 0.985f) h->co_best_L = used;
     const float lsi_side = a > c ? a : c;
     const float imb = (lsi_side - b) / (span > 0 ? span : 1.0f);
     // (one 64-block step: the landscape is flat to 1-3 % per step around the best grid, and a measured neighbour is worth
