@@ -170,6 +170,11 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         t_begin = time.perf_counter()
         closest = closest2[state["k"] % len(closest2)]
         state["k"] += 1
+        # the stage timers (HIP events around every stage) are recorded on the steps whose timers are read: every fourth
+        sample = bool(record) and (state["k"] % 4 == 0 or not lsi_ms)
+        if sample != state.get("timers_on", True):
+            h.set_option("timers", 1 if sample else 0)
+            state["timers_on"] = sample
         # everything is enqueued back to back; the step's single host sync is the count read-back
         h.lsi_query_async(0, 1, e0, e1, cap, pairs)
         # once the handle has settled on running the two sides beside each other, the PIP query -- the longer
@@ -191,7 +196,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         t_main = time.perf_counter()
         h.sync()  # joins the PIP kernels, which run on the handle's second stream beside the LSI kernel
         t_all = time.perf_counter()
-        if record and (state["k"] % 4 == 0 or not lsi_ms):  # (one call for all stages, every fourth step: it sits between two steps)
+        if sample:  # (one call for all stages, every fourth step: it sits between two steps)
             ms = h.last_ms_all()
             if DEBUG_PHASES and world == 1:
                 phases.append((t_begin, t_enq, t_main, t_all, time.perf_counter()))
@@ -220,6 +225,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             return timed_steps(k, with_gather)
         finally:
             gc.enable()
+            h.set_option("timers", 1)  # (everything outside the timed steps reads its timers)
+            state["timers_on"] = True
 
     def timed_steps(k, with_gather):
         barrier()

@@ -259,6 +259,9 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
  * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
  * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;
+ * "timers" 1 (default) / 0: whether the stage timers behind rj_last_ms / rj_last_ms_all are recorded (two event records
+ * per stage; a step of a join has four stages: ~1 % of a 0.9 ms step).  With 0, rj_last_ms keeps returning the values of
+ * the last recorded query; while "pip_concurrent" 2 is still trying schedules the timers are recorded regardless;
  * "lsi_points_split" -1 (default) / 0 / 1: how rj_lsi_points* produce the records -- 1: k_lsi_points decides each stored
  * coordinate from one exact floor division (no gcd: 98-99 % of the pairs of map-like data) and k_lsi_points_gcd simplifies
  * the rational (rational.h:198-203) only for the pairs that declines; 0: k_lsi_points_gcd for every pair, one latency

@@ -150,6 +150,7 @@ struct rj_handle_s {
   uint32_t* slow_list = nullptr;
   uint64_t slow_cap = 0;
   int flip_slow = 0;
+  int timers = 1;                          // "timers": 1 (default) the stage timers behind rj_last_ms are recorded, 0 they are not
   int points_split = -1;                   // "lsi_points_split": -1 by the last count (default), 0 never, 1 always
   int last_points_split = 0;               // what the last records launch did
   unsigned long long* d_stats = nullptr;    // [16]
@@ -401,8 +402,11 @@ int set_device(rj_handle h) {
   return RJ_OK;
 }
 
-void tic(rj_handle h, int t, hipStream_t st = nullptr) { (void) hipEventRecord(h->ev[t][0], st ? st : h->stream); }
-void toc(rj_handle h, int t, hipStream_t st = nullptr) { (void) hipEventRecord(h->ev[t][1], st ? st : h->stream); h->ev_valid[t] = true; }
+// ("timers" 0: no event records -- eight per step of a join, ~1.2 % of the headline step; while "pip_concurrent" 2 is
+//  still trying schedules the records stay, it decides by them)
+static inline bool timers_off(rj_handle h) { return !h->timers && !(h->pip_concurrent == 2 && h->co_choice < 0); }
+void tic(rj_handle h, int t, hipStream_t st = nullptr) { if (timers_off(h)) return; (void) hipEventRecord(h->ev[t][0], st ? st : h->stream); }
+void toc(rj_handle h, int t, hipStream_t st = nullptr) { if (timers_off(h)) return; (void) hipEventRecord(h->ev[t][1], st ? st : h->stream); h->ev_valid[t] = true; }
 // wait for a concurrent PIP before anything that frees, rebuilds or consumes what it touches
 hipError_t join_aux(rj_handle h) {
   if (!h->aux_pending) return hipSuccess;
@@ -615,6 +619,7 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strncmp(name, "pip_schedule_us", 15) && name[15] >= '0' && name[15] <= '2' && !name[16])  // best span seen per schedule, microseconds (-1: not measured)
     *value = h->co_best[name[15] - '0'] < 1e29f ? (int64_t) (h->co_best[name[15] - '0'] * 1000.0f) : -1;
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
+  else if (!strcmp(name, "timers")) *value = h->timers;
   else if (!strcmp(name, "lsi_points_split")) *value = h->points_split;
   else if (!strcmp(name, "lsi_points_last_split")) *value = h->last_points_split;
   else if (!strcmp(name, "lsi_points_gcd_pairs")) {  // pairs the last two-kernel records launch left to the gcd leg (synchronises the main stream)
@@ -651,6 +656,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "leaf_order")) {
     if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
     h->leaf_order = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "timers")) {
+    if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "timers: 0 or 1");
+    h->timers = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "lsi_points_split")) {

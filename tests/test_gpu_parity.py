@@ -574,3 +574,32 @@ def test_records_by_either_form_equal_the_oracle(oracle, split):
         ref2 = oracle.lsi_points(m0, m1, np.ascontiguousarray(got2["eid"]))
         assert np.array_equal(got2["x_num"], ref2["x_num"]) and np.array_equal(got2["y_num"], ref2["y_num"]), name
         dctx.close()
+
+
+def test_timers_off_changes_nothing_but_the_timers(oracle, lattice_pair):
+    """"timers" 0: the stage timers are not recorded (rj_last_ms keeps the last recorded values), results are the same;
+    while "pip_concurrent" 2 is still trying schedules they are recorded regardless -- it decides by them."""
+    ctx, dctx = lattice_pair
+    h = dctx.handle
+    m0, m1 = _omap(oracle, ctx.maps[0]), _omap(oracle, ctx.maps[1])
+    want = oracle.lsi_grid(m0, m1, 512)
+    cap = 2 * len(want)
+    pairs = h.alloc(8 * cap)
+    n_pts = ctx.maps[1].n_points
+    closest, faces = h.alloc(4 * n_pts), h.alloc(4 * n_pts)
+    assert h.lsi_query(0, 1, 0, ctx.maps[1].n_edges, cap, pairs) == len(want)
+    before = h.last_ms(_capi.RJ_T_LSI_KERNEL)
+    assert before > 0
+    try:
+        h.set_option("timers", 0)
+        assert h.get_option("timers") == 0
+        assert h.lsi_query(0, 1, 0, ctx.maps[1].n_edges, cap, pairs) == len(want)
+        assert h.last_ms(_capi.RJ_T_LSI_KERNEL) == before  # not re-recorded
+        h.pip_query(0, 1, None, 0, n_pts, closest, faces)
+        assert np.array_equal(closest.to_host(np.uint32), oracle.pip_brute(m0, 1, ctx.maps[1].pts))
+        with pytest.raises(_capi.RayJoinError):
+            h.set_option("timers", 2)
+    finally:
+        h.set_option("timers", 1)
+    assert h.lsi_query(0, 1, 0, ctx.maps[1].n_edges, cap, pairs) == len(want)
+    assert h.last_ms(_capi.RJ_T_LSI_KERNEL) > 0
