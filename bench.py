@@ -198,13 +198,14 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         t_all = time.perf_counter()
         if sample:  # (one call for all stages, every fourth step: it sits between two steps)
             ms = h.last_ms_all()
-            if DEBUG_PHASES and world == 1:
-                phases.append((t_begin, t_enq, t_main, t_all, time.perf_counter()))
+
             lsi_ms.append(ms[_capi.RJ_T_LSI_KERNEL])
             pip_ms.append(ms[_capi.RJ_T_PIP_KERNEL])
             pts_ms.append(ms[_capi.RJ_T_LSI_POINTS])
             if state["two_pass"]:
                 walk_ms.append(ms[_capi.RJ_T_PIP_WALK])
+        if DEBUG_PHASES and record and world == 1:
+            phases.append((t_begin, t_enq, t_main, t_all, time.perf_counter()))
         if pg is not None and with_gather:  # all-gather of this step's PIP result queue, behind the next step's kernels
             pg.begin(closest)
         state["n"] = n
@@ -240,6 +241,10 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         state["step_ms"] = [(b - a) * 1e3 for a, b in zip([t0] + marks, marks)]  # (this rank's host clock per step)
         if DEBUG_PHASES and rank == 0 and phases:
             ph = np.array(phases[-k:]) * 1e3
+            tot = ph[:, 4] - ph[:, 0]
+            for row in ph[tot > 2 * np.median(tot)]:  # a stalled step: where did the time go?
+                print("slow step: enqueued %.3f, main stream done %.3f, all done %.3f, timers read %.3f ms after its begin"
+                      % tuple(row[i] - row[0] for i in (1, 2, 3, 4)), file=sys.stderr)
             print("host phases, mean ms from step begin: enqueued %.3f, main stream done %.3f, all done %.3f, timers read %.3f"
                   % tuple((ph[:, i] - ph[:, 0]).mean() for i in (1, 2, 3, 4)), file=sys.stderr)
         if os.environ.get("RJ_BENCH_STEP_TIMES") and rank == 0:  # debug: each step's wall time, to stderr
