@@ -443,8 +443,9 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
     // pair of a workload -- so the second shared trial corrects it by what the first one showed: the side that ended
     // later gets more of the chip.
     const int used = h->lsi_share_blocks();
-    // (the neighbour has to win by more than the noise of one sample, 1.5 %: near a tie the grid the sweep's fit gives stays)
-    if (h->co_best_L == 0 || span < h->co_best[1] * 0.985f) h->co_best_L = used;
+    // (the neighbour has to win by 3 % -- one sample's noise plus what the first shared pair of a workload pays for
+    //  being the first: near a tie the grid the sweep's fit gives stays)
+    if (h->co_best_L == 0 || span < h->co_best[1] * 0.97f) h->co_best_L = used;
     const float lsi_side = a > c ? a : c;
     const float imb = (lsi_side - b) / (span > 0 ? span : 1.0f);
     // (one 64-block step: the landscape is flat to 1-3 % per step around the best grid, and a measured neighbour is worth
