@@ -855,7 +855,8 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     // slot.  Half-full leaves of 32 edges measured better there on BOTH kernels (WaterBodies stand-in, 10-edge chains:
     // k_lsi 1.29 vs 1.49 ms with 64, 1.37 Hilbert; PIP 1.75 vs 1.88 / 1.88) and worse where chains are long (USCounty:
     // PIP 0.87 vs 0.74): the cap follows the mean chain length.
-    const uint64_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
+    uint64_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
+    if (const char* e = getenv("RJ_RUN_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 64) cap_edges = (uint64_t) v; }  // (experiments)
     const RunSet R = stitch_runs(xy.data(), mm.h_edge_begin, cap_edges);
     mm.runs_cut = true;
     mm.nruns = R.run_first.size() - 1;
