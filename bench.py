@@ -502,8 +502,8 @@ def main():
 
 def run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1):
     """Size-independent properties at full size (no oracle can run here in seconds):
-    role symmetry, shard additivity, sortedness/uniqueness, permutation invariance of PIP,
-    and the two-pass PIP against k_pip alone."""
+    role symmetry, shard additivity, sortedness/uniqueness, the two forms of the records kernel against each other,
+    permutation invariance of PIP, and the two-pass PIP against k_pip alone."""
     res = {}
     h.sort_pairs(pairs, n_x)
     a = pairs[:n_x].to(torch.int64)
@@ -526,6 +526,16 @@ def run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1):
     both = torch.cat([pa[:na], pb[:nb]])
     h.sort_pairs(both, na + nb)
     res["shard_additivity"] = bool(na + nb == n_x and torch.equal(both, pairs[:n_x]))
+    # the 48-byte records: the gcd-free kernel + the gcd kernel over what it declines against the gcd kernel over every
+    # pair (two implementations of the narrowing store, bit for bit on every record of the step)
+    if n_x:
+        r1 = torch.empty((n_x, 6), dtype=torch.int64, device=dev)
+        r2 = torch.empty((n_x, 6), dtype=torch.int64, device=dev)
+        keep = h.get_option("lsi_points_split")
+        h.set_option("lsi_points_split", 1); h.lsi_points(pairs, n_x, r1)
+        h.set_option("lsi_points_split", 0); h.lsi_points(pairs, n_x, r2)
+        h.set_option("lsi_points_split", keep)
+        res["records_two_kernels_equal_one"] = bool(torch.equal(r1, r2))
     # PIP permutation invariance on a 1 M-point sample
     npts = min(1 << 20, query.n_points)
     pts = torch.from_numpy(query.pts[:npts]).to(dev)
