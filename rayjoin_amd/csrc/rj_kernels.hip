@@ -1534,7 +1534,9 @@ __global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A, Pi
     uint32_t slot[kWalkList];
 #pragma unroll
     for (int r = 0; r < kWalkList; r++) slot[r] = A.todo[(uint64_t) i * kWalkList + r];  // (one round trip for the record)
-    const int64_t px = A.pts[2 * ip], py = A.pts[2 * ip + 1];
+    typedef long long ll2_t __attribute__((ext_vector_type(2)));
+    const ll2_t pxy = reinterpret_cast<const ll2_t*>(A.pts)[ip];  // (one 16-byte request)
+    const int64_t px = pxy.x, py = pxy.y;
     double best_yy = __builtin_inf();
     uint32_t best_slot = 0xFFFFFFFFu;
     Seg best_seg = {0, 0, 0, 0};
@@ -1547,13 +1549,15 @@ __global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A, Pi
     // y-range overlaps the best so far.
     int64_t best_lo = INT64_MAX, best_hi = INT64_MAX;  // exact y-range of the best edge (its xsect_y lies inside, to 2^-6)
     bool best_exact = false;                           // best_yy has been computed
-    Seg cur = {0, 0, 0, 0};
+    Seg cur = {0, 0, 0, 0}, nxt = {0, 0, 0, 0};  // (two requests in flight: most listed points hold two or three candidates)
     if (slot[0] != 0xFFFFFFFFu) cur = T.sseg[slot[0]];
+    if (slot[1] != 0xFFFFFFFFu) nxt = T.sseg[slot[1]];
 #pragma unroll
     for (int r = 0; r < kWalkList; r++) {
       if (slot[r] == 0xFFFFFFFFu) break;
       const Seg e = cur;
-      if (r + 1 < kWalkList && slot[r + 1] != 0xFFFFFFFFu) cur = T.sseg[slot[r + 1]];
+      cur = nxt;
+      if (r + 2 < kWalkList && slot[r + 2] != 0xFFFFFFFFu) nxt = T.sseg[slot[r + 2]];
       const int64_t x_min = e.x1 < e.x2 ? e.x1 : e.x2, x_max = e.x1 < e.x2 ? e.x2 : e.x1;
       if (px < x_min || px > x_max || px == (A.query_map_id == 0 ? x_min : x_max)) continue;  // pip.h:44-46, in integers
       const int64_t ylo = e.y1 < e.y2 ? e.y1 : e.y2, yhi = e.y1 < e.y2 ? e.y2 : e.y1;
