@@ -259,6 +259,11 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
  * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
  * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;
+ * "pip_walk_points" 2 (default) / 1: query points per lane of the PIP walk.  2: k_pip_walk2 takes 128 consecutive query
+ * positions per wave through one traversal (node expansions, pops and the leaf blocks' loads shared by two point sets)
+ * where the query set fills 64-position groups, the base tree has at most 3 levels above its leaf blocks and no visit
+ * counters are being collected; k_pip_walk (one point per lane) otherwise, and always with 1.  Same results either way;
+ * rj_get_option "pip_last_walk_points" says what the last PIP query ran;
  * "timers" 1 (default) / 0: whether the stage timers behind rj_last_ms / rj_last_ms_all are recorded (two event records
  * per stage; a step of a join has four stages: ~1 % of a 0.9 ms step).  With 0, rj_last_ms keeps returning the values of
  * the last recorded query; while "pip_concurrent" 2 is still trying schedules the timers are recorded regardless;

@@ -136,6 +136,7 @@ struct rj_handle_s {
   int flip_lsi = 0, flip_pip[2] = {0, 0};  // which of the two counter sets the next launch uses (LSI; PIP on main / aux stream)
   // PIP in two passes (rj_kernels.hip, k_pip_walk): the integer-only walk settles what it can, k_pip takes the rest
   int pip_walk = 1;                        // "pip_walk": 1 auto (default), 0 k_pip alone, 2 always both passes
+  int last_walk_points = 1;                // ... and how many points a lane of its walk took
   int last_passes = 0;                     // kernels of the last PIP query (3 or 1)
   int flip_walk[2] = {0, 0};
   uint32_t* rest[2] = {nullptr, nullptr};  // per stream (main / aux): points the walk left to k_pip (grow-only)
@@ -150,6 +151,7 @@ struct rj_handle_s {
   uint32_t* slow_list = nullptr;
   uint64_t slow_cap = 0;
   int flip_slow = 0;
+  int walk_points = 2;                     // "pip_walk_points": 2 (default): k_pip_walk2, two query points per lane, where it applies; 1: k_pip_walk always
   int timers = 1;                          // "timers": 1 (default) the stage timers behind rj_last_ms are recorded, 0 they are not
   int points_split = -1;                   // "lsi_points_split": -1 by the last count (default), 0 never, 1 always
   int last_points_split = 0;               // what the last records launch did
@@ -510,6 +512,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (!h) return RJ_E_NOMEM;
   h->device = device_id;
   if (const char* e = getenv("RJ_LEAF_ORDER")) h->leaf_order = atoi(e) == 0 ? 0 : 1;
+  if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
   if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
   {
     hipDeviceProp_t prop;
@@ -621,6 +624,8 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
     *value = h->co_best[name[15] - '0'] < 1e29f ? (int64_t) (h->co_best[name[15] - '0'] * 1000.0f) : -1;
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
   else if (!strcmp(name, "timers")) *value = h->timers;
+  else if (!strcmp(name, "pip_walk_points")) *value = h->walk_points;
+  else if (!strcmp(name, "pip_last_walk_points")) *value = h->last_walk_points;
   else if (!strcmp(name, "lsi_points_split")) *value = h->points_split;
   else if (!strcmp(name, "lsi_points_last_split")) *value = h->last_points_split;
   else if (!strcmp(name, "lsi_points_gcd_pairs")) {  // pairs the last two-kernel records launch left to the gcd leg (synchronises the main stream)
@@ -657,6 +662,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "leaf_order")) {
     if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
     h->leaf_order = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "pip_walk_points")) {
+    if (value != 1 && value != 2) return fail(h, RJ_E_INVALID, "pip_walk_points: 1 or 2");
+    h->walk_points = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "timers")) {
@@ -1294,6 +1304,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     RJ_HIP(h, hipStreamSynchronize(h->stream));
   }
   h->last_passes = walk ? 3 : 1;
+  h->last_walk_points = 1;
   tic(h, RJ_T_PIP_KERNEL, st);
   if (n && walk) {
     const int wflip = h->capturing ? 0 : h->flip_walk[si];
@@ -1305,8 +1316,21 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     w.next_rest_count = h->d_counter + kRestCountWord + 2 * si + (1 - wflip);
     w.todo = h->todo[si]; w.todo_mask = h->todo_mask[si];
     if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
+    // Two points per lane (k_pip_walk2: one traversal per 128 positions) where the query set is large enough for full
+    // 64-position groups, the tree is low enough for six such blocks per CU (<= 3 levels above the leaf blocks: headline
+    // step -5.5 %, Zipcode -6 %, nested -5 %; a 5-level tree's stack leaves room for 5, and there the one-point kernel
+    // on 7 blocks is as fast or faster: WaterBodies +2 %, LakesNA +-0) and nobody is counting visits.
+    const bool two = h->walk_points == 2 && !h->stats_on && w.group_lanes == 64 && !h->chunk_groups &&
+                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6;
     tic(h, RJ_T_PIP_WALK, st);
-    RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
+    if (two) {
+      if (aux && h->lsi_shared && !h->pip_share_set)
+        walk_blocks = h->cus * pip_walk2_blocks_beside(w.bvh.top, h->lsi_share_blocks() / h->cus < 1 ? 1 : h->lsi_share_blocks() / h->cus);
+      RJ_HIP(h, launch_pip_walk2(st, w, walk_blocks, h->cus));
+      h->last_walk_points = 2;
+    } else {
+      RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
+    }
     if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
     toc(h, RJ_T_PIP_WALK, st);
     if (!h->capturing) h->flip_walk[si] = 1 - wflip;

@@ -1504,6 +1504,211 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 }
 
 
+// k_pip_walk with TWO points per lane: a wave takes 128 consecutive query positions (lane l: positions l and 64 + l of
+// the group) through ONE traversal -- node expansions, pops, the leaf blocks' loads and bucket-table reads are shared,
+// the per-point work (pop-time test, bucket lookup, scan, candidate bookkeeping) is done per point set, and a set none
+// of whose lanes wants a leaf block skips it (wave-uniform).  Same stack bound, twice the candidate lists; the hand-over
+// (one todo slot per position, one mask per 64 positions, the rest list) is exactly k_pip_walk's, so k_pip_exact
+// cannot tell the two apart.  Requires group_lanes == 64 (a large query set).
+__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256 * 2; }
+
+__global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
+  extern __shared__ uint4 walk_smem[];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  const DeviceBvh& T = A.bvh;
+  const int stack_cap = walk_stack_entries(T.top);
+  uint4* const stack = walk_smem + (size_t) wib * (walk2_wave_lds(T.top) / 16);
+  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [2][kWalkList][64], bank = lane
+  const uint32_t stack_lds = (uint32_t) (uintptr_t) stack;
+  const uint64_t ngroups = (A.n + 127) / 128;
+  const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
+  int part = blockIdx.x & 7, tried = 0;
+  __shared__ unsigned long long ranges[4];
+  if (threadIdx.x < 4) ranges[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;  // (see k_lsi)
+  if (blockIdx.x == 0 && threadIdx.x == 8) *A.next_rest_count = 0;
+  __syncthreads();
+  for (;;) {
+    uint32_t g32 = 0;
+    if (!next_group<4>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
+    typedef long long ll2_t __attribute__((ext_vector_type(2)));
+    int32_t qx[2], qy[2], qym1[2], qbest[2], sure_y0[2];
+    uint32_t cand_base[2], cand_at[2], ip[2];
+    bool valid[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
+      valid[p] = ipos < A.n;
+      ip[p] = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
+      qx[p] = 0; qy[p] = 0;
+      if (valid[p]) {
+        const ll2_t pt = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip[p]);
+        qx[p] = quant(pt.x);
+        qy[p] = quant(pt.y);
+      }
+      qym1[p] = qy[p] > 0 ? qy[p] - 1 : 0;
+      qbest[p] = valid[p] ? 0x7FFFFFFF : -1;
+      cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
+      cand_at[p] = cand_base[p];
+      sure_y0[p] = INT32_MIN;
+    }
+    int32_t gx0, gx1, gy0;
+    {
+      const int32_t a0 = valid[0] ? qx[0] : kEmptyMin, a1 = valid[1] ? qx[1] : kEmptyMin;
+      const int32_t b0 = valid[0] ? qx[0] : kEmptyMax, b1 = valid[1] ? qx[1] : kEmptyMax;
+      const int32_t c0 = valid[0] ? qy[0] : kEmptyMin, c1 = valid[1] ? qy[1] : kEmptyMin;
+      gx0 = a0 < a1 ? a0 : a1; gx1 = b0 > b1 ? b0 : b1; gy0 = c0 < c1 ? c0 : c1;
+    }
+    wave_min_max_min(gx0, gx1, gy0);
+    int32_t gbest = 0x7FFFFFFF;  // wave max of both sets' qbest
+
+    auto refine_if_many = [&](const QBox& b, uint64_t um) -> uint64_t {
+      if (__popcll(um) <= kPipRefineAbove) return um;
+      uint64_t keep = 0;
+      while (um) {
+        const int c = __builtin_ctzll(um);
+        um &= um - 1;
+        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
+        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
+        if (__ballot(ray_can_hit(qx[0], qym1[0], qbest[0], cx0, cy0, cx1, cy1) || ray_can_hit(qx[1], qym1[1], qbest[1], cx0, cy0, cx1, cy1)))
+          keep |= 1ull << c;
+      }
+      return keep;
+    };
+    int sp = 0;
+    {
+      const QBox b = T.lvl[T.top][lane];
+      const uint64_t higher = sibling_order(T, T.top)[lane];
+      uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
+      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+      if ((m >> lane) & 1)
+        stack[__popcll(m & higher)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
+      sp = __popcll(m);
+      wave_lds_fence();
+    }
+    while (sp > 0) {
+      --sp;
+      uint4 ent;
+      asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ent) : "v"(stack_lds + (uint32_t) sp * 16u) : "memory");
+      const int32_t ey0 = (int32_t) ent.y, ex0 = (int32_t) ent.z, ex1 = (int32_t) ent.w;
+      bool want[2];
+#pragma unroll
+      for (int p = 0; p < 2; p++) want[p] = ((qx[p] - ex0) | (ex1 - qx[p]) | (qbest[p] - ey0)) >= 0;
+      if (!__ballot(want[0] || want[1])) continue;  // stale: untouched
+      const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
+      const int lvl = (int) (e >> 28);
+      const uint32_t idx = e & 0x0FFFFFFFu;
+      if (lvl > 1) {
+        const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
+        const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane];
+        uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+        if ((m >> lane) & 1)
+          stack[sp + __popcll(m & higher)] =
+              make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
+        sp += __popcll(m);
+        wave_lds_fence();
+      } else {
+        const uint32_t slot0 = idx * 64;
+        const QBox bb = T.box0[(uint64_t) slot0 + lane];  // one base segment per lane, sorted by x0
+        const uint2 tab = T.xtab[(uint64_t) slot0 + lane];
+        const uint32_t sx0s = __builtin_amdgcn_readfirstlane((uint32_t) ex0);
+        const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
+        bool changed = false;
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          if (!__ballot(want[p])) continue;  // none of this set's points is under this block
+          const uint32_t bk = want[p] ? ((uint32_t) qx[p] - sx0s) >> sh : 0u;
+          const uint32_t bsh = (bk & 3u) * 8u;
+          const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+          const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+          int j = (int) hi - 1, jlo = (int) lo;
+          {
+            const int32_t top_x0 = __builtin_amdgcn_ds_bpermute(j << 2, bb.x0);
+            const int32_t low_x1 = __builtin_amdgcn_ds_bpermute(jlo << 2, bb.x1);
+            j -= top_x0 > qx[p] ? 1 : 0;
+            jlo += low_x1 < qx[p] ? 1 : 0;
+          }
+          j = want[p] ? j : -1;
+          jlo = want[p] ? jlo : 0;
+          const int32_t qbest_before = qbest[p];
+          while (__ballot(j >= jlo)) {
+            const int jj = j & 63;
+            const int ja = j << 2;
+            const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, bb.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, bb.x1);
+            const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, bb.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, bb.y1);
+            if (((qx[p] - sx0) | (sx1 - qx[p]) | (sy1 - qym1[p]) | (qbest[p] - sy0) | (j - jlo)) >= 0) {
+              const bool certain = sx0 < qx[p] && qx[p] < sx1 && sy0 > qy[p];
+              const bool replace = certain && sy1 < sure_y0[p];
+              const bool first = cand_at[p] == cand_base[p];
+              const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
+              cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot0 + (uint32_t) jj;
+              sure_y0[p] = (replace || (first && certain)) ? sy0 : INT32_MIN;
+              cand_at[p] += replace ? 0u : 64u;
+              const int32_t top = certain ? sy1 + 1 : 0x7FFFFFFF;
+              qbest[p] = over ? -1 : (top < qbest[p] ? top : qbest[p]);
+            }
+            j--;
+          }
+          changed = changed || qbest[p] != qbest_before;
+        }
+        if (__ballot(changed)) {
+          const int32_t gbest_before = gbest;
+          gbest = wave_max(qbest[0] > qbest[1] ? qbest[0] : qbest[1]);
+          if (gbest < gbest_before && sp > 1) {  // sweep the stack once: drop every entry that starts above the group's bound
+            int kept = 0;
+            for (int base = 0; base < sp; base += 64) {
+              const int i = base + lane;
+              const bool have = i < sp;
+              uint4 en = make_uint4(0, 0, 0, 0);
+              if (have) en = stack[i];
+              const bool alive = have && (int32_t) en.y <= gbest;
+              const uint64_t am = __ballot(alive);
+              wave_lds_fence();
+              if (alive) stack[kept + rank_below(am)] = en;
+              kept += __popcll(am);
+            }
+            sp = kept;
+            wave_lds_fence();
+          }
+        }
+      }
+    }
+    // hand-over, per set: exactly k_pip_walk's
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
+      const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
+      if (done) {
+        const bool hit = cand_at[p] != cand_base[p];
+        const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
+        __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip[p]);
+        if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip[p]);
+      }
+      const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
+      const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
+      const bool rest = valid[p] && !done && !listed;
+      if (listed) {
+#pragma unroll
+        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
+      }
+      const uint64_t lm = __ballot(listed);
+      const uint64_t g64 = (uint64_t) g32 * 2 + p;  // the 64-position group this set is
+      if (lane == 0 && g64 * 64 < A.n) A.todo_mask[g64] = lm;
+      const uint64_t rm = __ballot(rest);
+      if (rm) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A.rest_count, (unsigned long long) __popcll(rm));
+        base = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) base);
+        if (rest) A.rest[base + rank_below(rm)] = ip[p];
+      }
+    }
+    wave_lds_fence();  // (the lists are reused by the next group)
+  }
+}
+
+
 // The walk's leftovers: the exact predicate (pip.h:36-95, as in k_pip's evaluate) over each listed point's complete
 // candidate list.  A wave reads the masks of its share of the groups, compacts the listed positions into an LDS
 // queue (__ballot / mbcnt, like k_lsi's pair buffer) and evaluates 64 of them at a time, one point per lane: on a
@@ -1824,6 +2029,35 @@ hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int 
     hipLaunchKernelGGL(k_pip_walk<true>, dim3(grid), dim3(256), lds, st, a);
   else
     hipLaunchKernelGGL(k_pip_walk<false>, dim3(grid), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+int pip_walk2_blocks_per_cu(int top) {
+  const size_t block = 4 * walk2_wave_lds(top) + 64;
+  const size_t by_lds = (size_t) 160 * 1024 / block;
+  return (int) (by_lds < 6 ? by_lds : 6);
+}
+
+// ... beside `lsi_blocks_per_cu` resident blocks of k_lsi (17.5 KiB of LDS and one wave slot per SIMD each)
+int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu) {
+  const size_t block = 4 * walk2_wave_lds(top) + 64;
+  const size_t left = (size_t) 160 * 1024 > (size_t) lsi_blocks_per_cu * 17920 ? (size_t) 160 * 1024 - (size_t) lsi_blocks_per_cu * 17920 : 0;
+  int n = (int) (left / block);
+  if (n > 8 - lsi_blocks_per_cu) n = 8 - lsi_blocks_per_cu;
+  if (n > pip_walk2_blocks_per_cu(top)) n = pip_walk2_blocks_per_cu(top);
+  return n < 1 ? 1 : n;
+}
+
+hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a_in, int max_blocks, int cus) {
+  PipArgs a = a_in;
+  const size_t lds = 4 * walk2_wave_lds(a.bvh.top);
+  const int res = cus * pip_walk2_blocks_per_cu(a.bvh.top);
+  a.group_lanes = 64;  // (positions per mask; a wave takes two of them)
+  const uint64_t ngroups = (a.n + 127) / 128;
+  a.chunk_groups = a.chunk_groups ? a.chunk_groups : 3;  // (128-point groups: the same 6 x 64 positions per chunk)
+  const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+  const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
+  hipLaunchKernelGGL(k_pip_walk2, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

@@ -186,3 +186,37 @@ def test_uscounty_zipcode_overlay_stages_full_size():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["bit_exact_vs_oracle"] is True and out["intersections"] > 10000
     assert out["map0_edges"] > 7_000_000 and out["map1_edges"] > 23_000_000
+
+
+def test_walk_two_points_per_lane_equals_one_and_the_single_kernel():
+    """k_pip_walk2 (128 positions per wave, "pip_walk_points" 2, the default where it applies) against k_pip_walk and
+    against k_pip alone on a nested pair large enough for full 64-position groups (2.6 M query vertices, a quarter of
+    them on base vertices): closest eids and face ids of every vertex, bit for bit; and it is what ran."""
+    ctx = maps.Context([synth.standin("USCounty", 0.3), synth.standin("NestedBlockGroup", 0.3)]).load()
+    base, query = ctx.maps
+    h = _capi.Handle(0)
+    h.upload_map(0, base.pts, base.row_index, base.left, base.right)
+    h.upload_map(1, query.pts, query.row_index, query.left, query.right)
+    h.build_lbvh(0)
+    n = query.n_points
+    assert n > 1 << 21
+    out = {}
+    for name, walk, pts in (("two", 2, 2), ("one", 2, 1), ("single", 0, 1)):
+        h.set_option("pip_walk", walk)
+        h.set_option("pip_walk_points", pts)
+        c, f = h.alloc(4 * n), h.alloc(4 * n)
+        h.pip_query(0, 1, None, 0, n, c, f)
+        if walk:
+            assert h.get_option("pip_last_walk_points") == pts
+        out[name] = (c.to_host(np.uint32).copy(), f.to_host(np.int32).copy())
+    for other in ("one", "single"):
+        assert np.array_equal(out["two"][0], out[other][0]) and np.array_equal(out["two"][1], out[other][1]), other
+    assert (out["two"][0] != 0xFFFFFFFF).mean() > 0.5
+    # a sub-range whose length is not a multiple of 128 (the last wave's second point set is partly / wholly empty)
+    for m in (n - 37, (1 << 20) + 64 + 5):
+        c2 = h.alloc(4 * m)
+        h.set_option("pip_walk", 2); h.set_option("pip_walk_points", 2)
+        h.pip_query(0, 1, None, 0, m, c2, None)
+        assert np.array_equal(c2.to_host(np.uint32), out["single"][0][:m]), m
+    h.set_option("pip_walk", 1)
+    h.close()
