@@ -291,6 +291,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     else:
         n_x = state["n"]
     schedule = h.get_option("pip_schedule")  # (read now: a later index build starts the decision again)
+    state["walk_points"] = h.get_option("pip_last_walk_points")  # (which kernels the timed steps ran: one or two queries per lane)
+    state["lsi_segments"] = h.get_option("lsi_last_segments")
     share = (h.get_option("lsi_share_blocks"), h.get_option("pip_share_blocks"))
     pip_rest = h.get_option("pip_rest_aux" if schedule in (1, 2) else "pip_rest") if h.get_option("pip_walk") else None
     closest = state["closest"]
@@ -356,11 +358,12 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                 traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_* (counter passes: each kernel alone on its full grid)" % doc.get("tag")
             else:
                 prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
-        pip_kernel = "k_pip_walk" if state["two_pass"] else "k_pip"
+        pip_kernel = ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk") if state["two_pass"] else "k_pip"
+        lsi_kernel = "k_lsi2" if state["lsi_segments"] == 2 else "k_lsi"
         # the PIP query's dominant kernel: its own HIP-event time in the timed steps (the three PIP kernels together: query_ms)
         pip_dom_ms = walk_k if walk_k else pip_k
         roof = {}
-        for name, b, ms, kern in (("lsi", b_lsi, lsi_k, "k_lsi"), ("pip", b_pip, pip_dom_ms, pip_kernel)):
+        for name, b, ms, kern in (("lsi", b_lsi, lsi_k, lsi_kernel), ("pip", b_pip, pip_dom_ms, pip_kernel)):
             ach = b / (ms * 1e-3) / 1e9
             # `frac` prices the ALGORITHMIC bytes (every input once, every output once) against HBM peak: an
             # effective-throughput figure.  `traffic` = bytes the kernel actually moved (PMC), `traffic_frac` =
@@ -400,7 +403,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             # the two sides ran BESIDE each other in the timed steps: a kernel's duration there is not what it
             # needs alone, and the durations add up to more than the step -- say so, and add the solo figures
             for name, b, alone_ms in (("lsi", b_lsi, lsi_alone_ms), ("pip", b_pip, walk_alone_ms or pip_alone_ms)):
-                roof[name]["concurrent_with"] = pip_kernel if name == "lsi" else "k_lsi"
+                roof[name]["concurrent_with"] = pip_kernel if name == "lsi" else lsi_kernel
                 roof[name]["kernel_ms_alone"] = round(alone_ms, 4)
                 roof[name]["frac_alone"] = round(b / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
             roof["pip"]["query_ms_alone"] = round(pip_alone_ms, 4)
@@ -431,7 +434,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                                            -1: "k_lsi, then the PIP kernels (re-ordered query sets are never paired)" if never_paired
                                                else "undecided (fewer than 5 paired steps)"}[schedule],
                        "schedule_settled_before_timing": bool(settled),
-                       "pip_passes": ("k_pip_walk + k_pip_exact (its first blocks locate the %s points whose candidate list overflowed)" % pip_rest) if state["two_pass"]
+                       "pip_passes": ("%s + k_pip_exact (its first blocks locate the %s points whose candidate list overflowed)" % ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk", pip_rest)) if state["two_pass"]
                                      else "k_pip alone" + (" (the walk left %s lists to it: auto dropped the first pass)" % pip_rest if h.get_option("pip_walk") else "")},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,

@@ -259,6 +259,10 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
  * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
  * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;
+ * "lsi_segments" 2 (default) / 1: query segments per lane of the LSI kernel.  2: k_lsi2 takes 128 consecutive query
+ * segments per wave through one traversal where the query set is large (at least two full 64-segment groups per resident
+ * wave) and no visit counters are being collected; k_lsi otherwise, and always with 1.  Same pairs either way;
+ * rj_get_option "lsi_last_segments" says what the last LSI query ran;
  * "pip_walk_points" 2 (default) / 1: query points per lane of the PIP walk.  2: k_pip_walk2 takes 128 consecutive query
  * positions per wave through one traversal (node expansions, pops and the leaf blocks' loads shared by two point sets)
  * where the query set fills 64-position groups, the base tree has at most 3 levels above its leaf blocks and no visit

@@ -151,6 +151,8 @@ struct rj_handle_s {
   uint32_t* slow_list = nullptr;
   uint64_t slow_cap = 0;
   int flip_slow = 0;
+  int last_lsi_segments = 1;               // what the last LSI query ran
+  int lsi_segments = 2;                    // "lsi_segments": 2 (default): k_lsi2, two query segments per lane, where it applies; 1: k_lsi always
   int walk_points = 2;                     // "pip_walk_points": 2 (default): k_pip_walk2, two query points per lane, where it applies; 1: k_pip_walk always
   int timers = 1;                          // "timers": 1 (default) the stage timers behind rj_last_ms are recorded, 0 they are not
   int points_split = -1;                   // "lsi_points_split": -1 by the last count (default), 0 never, 1 always
@@ -512,6 +514,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (!h) return RJ_E_NOMEM;
   h->device = device_id;
   if (const char* e = getenv("RJ_LEAF_ORDER")) h->leaf_order = atoi(e) == 0 ? 0 : 1;
+  if (const char* e = getenv("RJ_LSI_SEGMENTS")) h->lsi_segments = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
   if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
   if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
   {
@@ -625,6 +628,8 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
   else if (!strcmp(name, "timers")) *value = h->timers;
   else if (!strcmp(name, "pip_walk_points")) *value = h->walk_points;
+  else if (!strcmp(name, "lsi_segments")) *value = h->lsi_segments;
+  else if (!strcmp(name, "lsi_last_segments")) *value = h->last_lsi_segments;
   else if (!strcmp(name, "pip_last_walk_points")) *value = h->last_walk_points;
   else if (!strcmp(name, "lsi_points_split")) *value = h->points_split;
   else if (!strcmp(name, "lsi_points_last_split")) *value = h->last_points_split;
@@ -662,6 +667,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "leaf_order")) {
     if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
     h->leaf_order = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "lsi_segments")) {
+    if (value != 1 && value != 2) return fail(h, RJ_E_INVALID, "lsi_segments: 1 or 2");
+    h->lsi_segments = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "pip_walk_points")) {
@@ -1070,7 +1080,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (h->lsi_shared && h->lsi_share_blocks() < max_blocks) max_blocks = h->lsi_share_blocks();
   tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
   if (qe > qb) {
-    RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks));
+    RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks, h->lsi_segments, &h->last_lsi_segments));
     if (!h->capturing) h->flip_lsi = 1 - flip;
   } else {
     RJ_HIP(h, hipMemsetAsync(a.counter, 0, 8, h->stream));  // (an empty query: nothing ran that could have counted)

@@ -126,7 +126,7 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
-hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks);
+hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks, int segs_per_lane = 1, int* segs_used = nullptr);
 hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                                uint64_t n, unsigned long long* out2);
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,

@@ -745,6 +745,147 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
   }
 }
 
+// k_lsi with TWO query segments per lane: a wave takes 128 consecutive query positions (lane l: positions l and 64 + l
+// of the group) through one traversal -- the pre-filter's verdict, the union box, node expansions, stack traffic and
+// the leaf blocks' loads are shared; the in-leaf scan runs per segment set, and a set with nothing in the block's
+// x-range skips it.  The kernel is bound by its chain of dependent node fetches per group, so twice the queries per
+// chain is most of twice the throughput per wave.  Candidate pairs and hits go through the same LDS buffers
+// (they carry the query eid), so everything behind the traversal is k_lsi's.  Requires group_lanes == 64.
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsi2(LsiArgs A) {
+  __shared__ LsiWaveLds lds[4];
+  const int lane = lane_id();
+  const int wib = threadIdx.x >> 6;
+  LsiWaveLds& L = lds[wib];
+  const uint64_t nq = A.qend - A.qbeg;
+  const uint64_t ngroups = (nq + 127) / 128;
+  const DeviceBvh& T = A.bvh;
+  if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 8) *A.next_counter = 0;
+  const bool occ_usable = T.occ[(size_t) kOccDim * kOccRowWords] == 0;  // every base segment was rasterised
+  const int stack_cap = kStackEntries;
+  int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
+  unsigned long long st_tests = 0;
+  const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
+  int part = blockIdx.x & 7, tried = 0;
+  for (;;) {
+  uint32_t chunk = 0;
+  if (!next_chunk(A.work_counter, nchunks, part, tried, lane, chunk)) break;
+  const uint64_t g_begin = (uint64_t) chunk * A.chunk_groups;
+  const uint64_t g_end = g_begin + A.chunk_groups < ngroups ? g_begin + A.chunk_groups : ngroups;
+  for (uint64_t g = g_begin; g < g_end; g++) {
+    uint64_t q[2];
+    bool near[2];
+    int32_t qx0[2], qy0[2], qx1[2], qy1[2];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      const uint64_t qi = g * 128 + (uint64_t) p * 64 + lane;
+      const bool valid = qi < nq;
+      q[p] = A.qbeg + (A.order ? (valid ? A.order[qi] : 0) : qi);
+      near[p] = valid;
+      if (valid && occ_usable) near[p] = occ_any_code(T.occ, __builtin_nontemporal_load(A.qcode + q[p]));
+    }
+    if (!__ballot(near[0] || near[1])) continue;  // both halves of the group are clear of the base map
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+      qx0[p] = kEmptyMin; qy0[p] = kEmptyMin; qx1[p] = kEmptyMax; qy1[p] = kEmptyMax;
+      if (near[p]) {
+        const Seg s = A.qseg[q[p]];
+        qx0[p] = quant(s.x1 < s.x2 ? s.x1 : s.x2);
+        qx1[p] = quant(s.x1 < s.x2 ? s.x2 : s.x1);
+        qy0[p] = quant(s.y1 < s.y2 ? s.y1 : s.y2);
+        qy1[p] = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+      }
+    }
+    const int32_t gx0 = wave_min(qx0[0] < qx0[1] ? qx0[0] : qx0[1]), gy0 = wave_min(qy0[0] < qy0[1] ? qy0[0] : qy0[1]);
+    const int32_t gx1 = wave_max(qx1[0] > qx1[1] ? qx1[0] : qx1[1]), gy1 = wave_max(qy1[0] > qy1[1] ? qy1[0] : qy1[1]);
+    auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
+      uint64_t keep = 0;
+      while (um) {
+        const int c = __builtin_ctzll(um);
+        um &= um - 1;
+        const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
+        const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
+        if (__ballot(boxes_overlap(qx0[0], qy0[0], qx1[0], qy1[0], cx0, cy0, cx1, cy1) ||
+                     boxes_overlap(qx0[1], qy0[1], qx1[1], qy1[1], cx0, cy0, cx1, cy1)))
+          keep |= 1ull << c;
+      }
+      return keep;
+    };
+    int sp = 0;
+    {  // top level: <= 64 nodes, one per lane
+      QBox b = T.lvl[T.top][lane];
+      uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
+      sp = __popcll(m);
+      wave_lds_fence();
+    }
+    auto process = [&](uint32_t e, const QBox& b, const uint2& tab) {
+      const int lvl = (int) (e >> 28);
+      const uint32_t idx = e & 0x0FFFFFFFu;
+      if (lvl > 1) {
+        uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
+        sp += __popcll(m);
+        wave_lds_fence();
+      } else {
+        const uint32_t slot0 = idx * 64;
+        const int32_t lx0 = wave_min(b.x0), lx1 = wave_max(b.x1);
+        const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+          const int32_t ca = qx0[p] > lx0 ? qx0[p] : lx0, cz = qx1[p] < lx1 ? qx1[p] : lx1;
+          const bool some = ca <= cz;
+          if (!__ballot(some)) continue;  // none of this set's segments reaches into the block's x-range
+          const uint32_t bhi = some ? (uint32_t) (cz - lx0) >> sh : 0u, blo = some ? (uint32_t) (ca - lx0) >> sh : 0u;
+          const uint32_t hi = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (bhi >> 2) << 2, (int) tab.x) >> ((bhi & 3u) * 8u)) & 0xFFu;
+          const uint32_t lo = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (blo >> 2) << 2, (int) tab.y) >> ((blo & 3u) * 8u)) & 0xFFu;
+          int j = some ? (int) hi - 1 : -1;
+          const int jlo = some ? (int) lo : 0;
+          while (__ballot(j >= jlo)) {
+            const int ja = j << 2;
+            const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, b.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, b.x1);
+            const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, b.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, b.y1);
+            const bool c = ((qx1[p] - sx0) | (sx1 - qx0[p]) | (qy1[p] - sy0) | (sy1 - qy0[p]) | (j - jlo)) >= 0;
+            const uint64_t cm = __ballot(c);
+            if (cm) {
+              if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q[p], slot0 + (uint32_t) (j & 63));
+              np += __popcll(cm);
+              wave_lds_fence();
+              if (np >= 64) lsi_drain<false>(L, np, nh, 64, A, lane, st_tests);
+            }
+            j--;
+          }
+        }
+      }
+    };
+    auto fetch = [&](uint32_t e, QBox& b, uint2& tab) {
+      const int lvl = (int) (e >> 28);
+      const uint64_t c = (uint64_t) (e & 0x0FFFFFFFu) * 64 + lane;
+      const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
+      b = src[c];
+      tab = T.xtab[lvl > 1 ? (uint64_t) lane : c];
+    };
+    while (sp > 0) {
+      const bool two = sp > 1;
+      const uint32_t ea = __builtin_amdgcn_readfirstlane(L.stack[sp - 1]);
+      const uint32_t eb = __builtin_amdgcn_readfirstlane(L.stack[two ? sp - 2 : sp - 1]);
+      sp -= two ? 2 : 1;
+      QBox ba, bb2;
+      uint2 ta, tb;
+      fetch(ea, ba, ta);
+      fetch(eb, bb2, tb);
+      process(ea, ba, ta);
+      if (two) process(eb, bb2, tb);
+    }
+  }
+  }
+  if (np > 0) lsi_drain<false>(L, np, nh, np, A, lane, st_tests);
+  if (nh >= 64) lsi_flush_hits<false>(L, nh, 64, A, lane);
+  if (nh > 0) lsi_flush_hits<false>(L, nh, nh, A, lane);
+}
+
 // =============================================================================================
 // LSI intersection points (per hit only): rational point, clamp, narrowing store
 // =============================================================================================
@@ -1934,12 +2075,30 @@ static uint32_t pick_group_lanes(uint64_t nqueries, int resident_blocks_, int bl
 // the headline pair (9 groups per walk wave): 1 group per chunk, walk 169 -> 232 us.
 static uint32_t pick_chunk_groups(uint32_t requested, uint32_t optimum) { return requested ? requested : optimum; }
 
-hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_blocks) {
+hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_blocks, int segs_per_lane, int* segs_used) {
   LsiArgs a = a_in;
+  if (segs_used) *segs_used = 1;
   const void* k = stats ? (const void*) k_lsi<true> : (const void*) k_lsi<false>;
   static int res[2] = {0, 0};
   if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
+  const bool auto_lanes = !a.group_lanes;
   if (!a.group_lanes) a.group_lanes = pick_group_lanes(a.qend - a.qbeg, res[stats]);
+  // two segments per lane (k_lsi2) where the query set fills 64-segment groups twice over and nobody is counting visits
+  if (segs_per_lane == 2 && !stats && auto_lanes && a.group_lanes == 64 && !a.chunk_groups &&
+      pick_group_lanes((a.qend - a.qbeg) / 2, res[0]) == 64) {
+    static int res2 = 0;
+    if (!res2) res2 = resident_blocks((const void*) k_lsi2, 1 << 20);
+    const uint64_t ngroups = (a.qend - a.qbeg + 127) / 128;
+    a.chunk_groups = 4;  // (128-segment groups: the same 8 x 64 positions per chunk)
+    const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
+    int grid = grid_for(nchunks, 4, res2 < max_blocks ? res2 : max_blocks);
+    const uint64_t by_work = ngroups / (4 * 10);  // (the small-query rule below, for groups of twice the size)
+    const int floor_blocks = 512 < grid ? 512 : grid;
+    if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
+    hipLaunchKernelGGL(k_lsi2, dim3(grid), dim3(256), 0, st, a);
+    if (segs_used) *segs_used = 2;
+    return hipGetLastError();
+  }
   uint64_t ngroups = (a.qend - a.qbeg + a.group_lanes - 1) / a.group_lanes;
   a.chunk_groups = pick_chunk_groups(a.chunk_groups, 8);
   uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;

@@ -22,7 +22,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # round 3: the dominant kernel is the PIP walk; the line says what the number is (algorithmic bytes vs moved bytes)
-    assert r["kernel"] in ("k_pip_walk", "k_lsi") and "query_ms" in (r if r["kernel"] == "k_pip_walk" else d["roofline_other"])
+    assert r["kernel"] in ("k_pip_walk", "k_pip_walk2", "k_lsi", "k_lsi2") and "query_ms" in (r if r["kernel"].startswith("k_pip_walk") else d["roofline_other"])
     if r.get("traffic"):
         assert 0 < r["traffic_frac"] < 1 and r["limiter"] in ("valu-issue", "dependent-load latency") and 0 < r["limiter_frac"] <= 1
     c = d["cpu_baseline"]
@@ -52,9 +52,10 @@ def test_traffic_file_matches_the_kernels_bench_reports():
     """profiles/traffic.json carries the PMC evidence bench.py quotes AND the hash of the kernel
     sources it was measured on; bench.py ignores it when that hash is not the tree's."""
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    assert {"k_lsi", "k_pip_walk", "k_pip_exact"} <= set(t["traffic"]) and all(v > 0 for v in t["traffic"].values())
+    lsi_k, walk_k = ("k_lsi2" if "k_lsi2" in t["traffic"] else "k_lsi"), ("k_pip_walk2" if "k_pip_walk2" in t["traffic"] else "k_pip_walk")
+    assert {lsi_k, walk_k, "k_pip_exact"} <= set(t["traffic"]) and all(v > 0 for v in t["traffic"].values())
     assert len(t["kernel_source_hash"]) == 16 and t["tag"].startswith("r")
-    for k in ("k_lsi", "k_pip_walk"):
+    for k in (lsi_k, walk_k):
         assert t["sq"][k]["SQ_ACTIVE_INST_VALU"] > 0 and t["sq"][k]["GRBM_GUI_ACTIVE"] > 0
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "kernel_source_hash" in src and "stale" in src
