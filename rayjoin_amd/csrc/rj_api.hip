@@ -136,6 +136,10 @@ struct rj_handle_s {
   int flip_lsi = 0, flip_pip[2] = {0, 0};  // which of the two counter sets the next launch uses (LSI; PIP on main / aux stream)
   // PIP in two passes (rj_kernels.hip, k_pip_walk): the integer-only walk settles what it can, k_pip takes the rest
   int pip_walk = 1;                        // "pip_walk": 1 auto (default), 0 k_pip alone, 2 always both passes
+  // k_pip_walk2 on a tree of more than 3 levels keeps 4 candidate slots per point instead of 6 (its stack is larger):
+  // where that overflows too many lists the one-point kernel takes the query size back (decided again with the schedule)
+  bool last_tall[2] = {false, false};      // the last walk on main / aux was such a one
+  uint64_t tall_bad_n = 0;                 // the query size for which it left too many lists over (0: none)
   int last_walk_points = 1;                // ... and how many points a lane of its walk took
   int last_passes = 0;                     // kernels of the last PIP query (3 or 1)
   int flip_walk[2] = {0, 0};
@@ -423,6 +427,7 @@ static void co_reset(rj_handle h) {
   h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0;
   h->co_ratio = 0.46f;
   h->co_L = h->co_best_L = 0;
+  h->tall_bad_n = 0;
 }
 static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
   if (!h->co_measure) return;
@@ -1285,7 +1290,10 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // how many points the last two-pass query of this size left to k_pip (either stream: the count belongs to the query)
   uint64_t seen = ~0ull;
   for (int k : {si, 1 - si})
-    if (seen == ~0ull && h->walk_n[k] == n && h->h_rest[k] != ~0ull) seen = h->h_rest[k];
+    if (seen == ~0ull && h->walk_n[k] == n && h->h_rest[k] != ~0ull) {
+      seen = h->h_rest[k];
+      if (h->last_tall[k] && seen > 8192) h->tall_bad_n = n;  // (4-slot lists overflow too often on this pair)
+    }
   // "auto" drops the first pass where it does not pay: most points left over, or many overflowed lists in absolute
   // terms -- k_pip locates those one scattered handful per wave (the list is in no useful order), which on the gaussian
   // polygons (25 k of 8 M) costs more than the walk saves
@@ -1327,11 +1335,14 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     w.todo = h->todo[si]; w.todo_mask = h->todo_mask[si];
     if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
     // Two points per lane (k_pip_walk2: one traversal per 128 positions) where the query set is large enough for full
-    // 64-position groups, the tree is low enough for six such blocks per CU (<= 3 levels above the leaf blocks: headline
-    // step -5.5 %, Zipcode -6 %, nested -5 %; a 5-level tree's stack leaves room for 5, and there the one-point kernel
-    // on 7 blocks is as fast or faster: WaterBodies +2 %, LakesNA +-0) and nobody is counting visits.
+    // 64-position groups and nobody is counting visits: headline step -5.5 %, Zipcode -6 %, nested -5 %.  On a tree of
+    // more than 3 levels the larger stack leaves room for 4 candidate slots per point instead of 6 (six blocks per CU
+    // either way): LakesNA step -8 %, but on WaterBodies 13.8 k lists overflow instead of 264 and the step is 18 %
+    // slower -- so a query size whose 4-slot run left more than 8 Ki lists over goes back to the one-point kernel.
+    const bool tall = w.bvh.top > 3;  // (k_pip_walk2 then keeps 4 candidate slots per point, see walk2_list)
     const bool two = h->walk_points == 2 && !h->stats_on && w.group_lanes == 64 && !h->chunk_groups &&
-                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6;
+                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6 && !(tall && h->tall_bad_n == n);
+    h->last_tall[si] = two && tall;
     tic(h, RJ_T_PIP_WALK, st);
     if (two) {
       if (aux && h->lsi_shared && !h->pip_share_set)

@@ -1651,8 +1651,12 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 // of whose lanes wants a leaf block skips it (wave-uniform).  Same stack bound, twice the candidate lists; the hand-over
 // (one todo slot per position, one mask per 64 positions, the rest list) is exactly k_pip_walk's, so k_pip_exact
 // cannot tell the two apart.  Requires group_lanes == 64 (a large query set).
-__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256 * 2; }
+// (LIST = candidate slots a lane keeps per point: kWalkList where the stack leaves room, 4 for the taller trees -- the
+//  todo record always holds kWalkList slots, the unused ones stay empty; more overflowed lists, one more block per CU)
+__host__ __device__ __forceinline__ int walk2_list(int top) { return top <= 3 ? kWalkList : 4; }
+__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) walk2_list(top) * 256 * 2; }
 
+template <int LIST>
 __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
   extern __shared__ uint4 walk_smem[];
   const int lane = lane_id();
@@ -1660,7 +1664,7 @@ __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
   const DeviceBvh& T = A.bvh;
   const int stack_cap = walk_stack_entries(T.top);
   uint4* const stack = walk_smem + (size_t) wib * (walk2_wave_lds(T.top) / 16);
-  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [2][kWalkList][64], bank = lane
+  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [2][LIST][64], bank = lane
   const uint32_t stack_lds = (uint32_t) (uintptr_t) stack;
   const uint64_t ngroups = (A.n + 127) / 128;
   const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
@@ -1690,7 +1694,7 @@ __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
       }
       qym1[p] = qy[p] > 0 ? qy[p] - 1 : 0;
       qbest[p] = valid[p] ? 0x7FFFFFFF : -1;
-      cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
+      cand_base[p] = (uint32_t) lane + (uint32_t) p * (LIST * 64);
       cand_at[p] = cand_base[p];
       sure_y0[p] = INT32_MIN;
     }
@@ -1783,7 +1787,7 @@ __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
               const bool certain = sx0 < qx[p] && qx[p] < sx1 && sy0 > qy[p];
               const bool replace = certain && sy1 < sure_y0[p];
               const bool first = cand_at[p] == cand_base[p];
-              const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
+              const bool over = !replace && cand_at[p] == cand_base[p] + LIST * 64;
               cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot0 + (uint32_t) jj;
               sure_y0[p] = (replace || (first && certain)) ? sy0 : INT32_MIN;
               cand_at[p] += replace ? 0u : 64u;
@@ -1828,11 +1832,11 @@ __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
         if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip[p]);
       }
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
-      const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
+      const bool listed = valid[p] && !done && fill <= (uint32_t) LIST;
       const bool rest = valid[p] && !done && !listed;
       if (listed) {
 #pragma unroll
-        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
+        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (k < LIST && (uint32_t) k < fill) ? cand[cand_base[p] + 64 * (k < LIST ? k : 0)] : 0xFFFFFFFFu;
       }
       const uint64_t lm = __ballot(listed);
       const uint64_t g64 = (uint64_t) g32 * 2 + p;  // the 64-position group this set is
@@ -2216,7 +2220,10 @@ hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a_in, int max_blocks,
   a.chunk_groups = a.chunk_groups ? a.chunk_groups : 3;  // (128-point groups: the same 6 x 64 positions per chunk)
   const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
-  hipLaunchKernelGGL(k_pip_walk2, dim3(grid), dim3(256), lds, st, a);
+  if (walk2_list(a.bvh.top) == kWalkList)
+    hipLaunchKernelGGL(k_pip_walk2<kWalkList>, dim3(grid), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(k_pip_walk2<4>, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
