@@ -1341,7 +1341,8 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     // slower -- so a query size whose 4-slot run left more than 8 Ki lists over goes back to the one-point kernel.
     const bool tall = w.bvh.top > 3;  // (k_pip_walk2 then keeps 4 candidate slots per point, see walk2_list)
     const bool two = h->walk_points == 2 && !h->stats_on && w.group_lanes == 64 && !h->chunk_groups &&
-                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6 && !(tall && h->tall_bad_n == n);
+                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6 && !(tall && h->tall_bad_n == n) &&
+                     n >= (uint64_t) 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top);  // (two 128-position groups per resident wave)
     h->last_tall[si] = two && tall;
     tic(h, RJ_T_PIP_WALK, st);
     if (two) {
