@@ -87,6 +87,11 @@ int rj_map_num_edges(rj_handle h, int map_id, uint64_t* ne);
 int rj_map_num_points(rj_handle h, int map_id, uint64_t* np);
 /* device pointer to the uploaded scaled points (int64 x,y pairs), owned by the handle */
 int rj_map_points_dev(rj_handle h, int map_id, const int64_t** pts_dev);
+/* inspection: the polyline runs rj_build_lbvh cut for this map on the device ("leaf_order" 1; the analogue of the
+ * reference's RT grouping, src/rt/primitive.h:120-260) -- piece p = eids [piece_begin[p], + piece_len[p]), run r =
+ * pieces [run_first[r], run_first[r + 1]).  Host arrays, any of them NULL to fetch only the counts. */
+int rj_map_runs(rj_handle h, int map_id, uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first,
+                uint64_t* nruns, uint64_t* npieces);
 
 /* replaces: Scaling(bb) + the scale pass of Map::LoadFrom (src/map/scaling.h:56-93, src/map/map.h:171-180)
  * for hosts that do not scale themselves: xy[2n] doubles -> out_xy[2n] scaled int64, bb = {min_x, min_y,
@@ -218,6 +223,7 @@ typedef enum {
   RJ_T_BUILD_SORT = 7,
   RJ_T_BUILD_LEAVES = 8,
   RJ_T_BUILD_LEVELS = 9,
+  RJ_T_BUILD_RUNS = 11, /* cutting the polyline runs on the device (the first rj_build_lbvh of a map with "leaf_order" 1; inside RJ_T_BUILD) */
   RJ_T_PIP_WALK = 10  /* k_pip_walk, the integer-only first pass of the last rj_pip_query* (RJ_T_PIP_KERNEL spans both passes) */
 } rj_timer;
 /* HIP-event time (ms) of the last launch of that stage on the handle's stream; syncs. */

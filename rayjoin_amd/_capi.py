@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RAYJOIN_AMD_LIB") or os.path.join(HERE, "librayjoin_a
 
 RJ_OK, RJ_E_INVALID, RJ_E_HIP, RJ_E_OVERFLOW, RJ_E_NOMEM, RJ_E_INTERNAL = 0, 1, 2, 3, 4, 5
 RJ_T_BUILD, RJ_T_LSI_KERNEL, RJ_T_PIP_KERNEL, RJ_T_LSI_POINTS, RJ_T_SORT, RJ_T_ORDER = 0, 1, 2, 3, 4, 5
-RJ_T_BUILD_KEYS, RJ_T_BUILD_SORT, RJ_T_BUILD_LEAVES, RJ_T_BUILD_LEVELS, RJ_T_PIP_WALK = 6, 7, 8, 9, 10
+RJ_T_BUILD_KEYS, RJ_T_BUILD_SORT, RJ_T_BUILD_LEAVES, RJ_T_BUILD_LEVELS, RJ_T_PIP_WALK, RJ_T_BUILD_RUNS = 6, 7, 8, 9, 10, 11
 MISS_EID = 0xFFFFFFFF
 
 XSECT_DTYPE = np.dtype(
@@ -34,6 +34,7 @@ SYMBOLS = {
     "rj_map_num_edges": (_int, [_vp, _int, C.POINTER(_u64)]),
     "rj_map_num_points": (_int, [_vp, _int, C.POINTER(_u64)]),
     "rj_map_points_dev": (_int, [_vp, _int, C.POINTER(_vp)]),
+    "rj_map_runs": (_int, [_vp, _int, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rj_build_lbvh": (_int, [_vp, _int]),
     "rj_lsi_query": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp, C.POINTER(_u64)]),
     "rj_lsi_query_async": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp]),
@@ -254,6 +255,16 @@ class Handle:
         self._check(self.L.rj_map_points_dev(self.h, map_id, C.byref(p)))
         return p.value
 
+    def map_runs(self, map_id):
+        """-> (piece_begin, piece_len, run_first) of the polyline runs cut for this map"""
+        nr, npc = _u64(), _u64()
+        self._check(self.L.rj_map_runs(self.h, map_id, None, None, None, C.byref(nr), C.byref(npc)))
+        pb = np.zeros(npc.value, dtype=np.uint32)
+        pl = np.zeros(npc.value, dtype=np.uint32)
+        rf = np.zeros(nr.value + 1, dtype=np.uint32)
+        self._check(self.L.rj_map_runs(self.h, map_id, pb.ctypes.data, pl.ctypes.data, rf.ctypes.data, None, None))
+        return pb, pl, rf
+
     def build_lbvh(self, base_map_id):
         self._check(self.L.rj_build_lbvh(self.h, base_map_id))
 
@@ -367,8 +378,8 @@ class Handle:
 
     def last_ms_all(self):
         """-> list of the last duration of every stage (RJ_T_* order), -1 where a stage has not run"""
-        buf = (C.c_float * 11)()
-        self._check(self.L.rj_last_ms_all(self.h, buf, 11))
+        buf = (C.c_float * 12)()
+        self._check(self.L.rj_last_ms_all(self.h, buf, 12))
         return list(buf)
 
     def last_stats(self):

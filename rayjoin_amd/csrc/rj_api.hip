@@ -28,10 +28,11 @@ struct MapState {
   uint32_t* ccode = nullptr;  // 4-byte cell code per edge (k_lsi's pre-filter stream)
   uint32_t* left = nullptr;
   uint32_t* right = nullptr;
-  std::vector<uint32_t> h_edge_begin;  // host copy of the first eid of every chain (+ sentinel): "leaf_order" 1 cuts its runs from it
-  // "leaf_order" 1: the polyline runs of this map (stitch_runs), cut on the host the first time an index of it is
-  // built and kept on the device: piece p = eids [piece_begin[p], + piece_len[p]), run r = pieces [run_first[r], run_first[r + 1])
+  uint32_t* edge_begin = nullptr;  // [nc + 1] first eid of every chain (+ sentinel): row_index[c] - c
+  // "leaf_order" 1: the polyline runs of this map, cut ON THE DEVICE (rj_stitch.hip) the first time an index of it is
+  // built and kept: piece p = eids [piece_begin[p], + piece_len[p]), run r = pieces [run_first[r], run_first[r + 1])
   bool runs_cut = false;
+  uint32_t run_cap = 0;  // edges a run may hold (what the runs were cut with)
   uint64_t nruns = 0, npieces = 0;
   uint32_t *piece_begin = nullptr, *piece_len = nullptr, *run_first = nullptr;
 };
@@ -62,7 +63,7 @@ struct GridState {  // -mode=grid: one CSR per map (rj_grid.hip)
   uint64_t total = 0;
 };
 
-constexpr int kNumTimers = 11;
+constexpr int kNumTimers = 12;
 // average (w + h) of a 64-query group's quantised box above which the query set is re-ordered
 // along the Morton curve before the kernels run (the domain is 2^31 wide per axis)
 constexpr unsigned long long kIncoherentExtent = 1ull << 28;
@@ -125,6 +126,9 @@ struct rj_handle_s {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   static constexpr int kGraphs = 4;   // captured steps per handle (e.g. one per result buffer of a double-buffered caller)
   int cap_id = 0;                    // the slot being captured
+  // which counter kinds the captured step uses (bit 0 LSI, 1 / 2 PIP on main / aux, 3 / 4 the walk on main / aux, 5 the
+  // records' list): a replay runs on set 0 of those and leaves set 1 cleared, so the next plain launch must take set 1
+  int cap_kinds = 0, graph_kinds[kGraphs] = {0};
   hipGraph_t graph[kGraphs] = {nullptr}, graph_aux[kGraphs] = {nullptr};  // one graph per stream: ROCm runs the branches of ONE
   hipGraphExec_t graph_exec[kGraphs] = {nullptr}, graph_exec_aux[kGraphs] = {nullptr};  // graph one after the other (measured)
   hipStream_t stream = nullptr;
@@ -186,6 +190,8 @@ struct rj_handle_s {
   void* ord_temp = nullptr;
   size_t ord_temp_bytes = 0;
   int leaf_order = 1;        // "leaf_order" (default 1, or RJ_LEAF_ORDER): what the NEXT rj_build_lbvh makes a leaf of
+  int debug_run_cap = 0;     // experiments: edges per polyline run (0: by the mean chain length)
+  uint32_t stitch_stats[3] = {0, 0, 0};  // the last run cutting: ranking rounds, incidences on closed loops, rounds of the second ranking
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
   int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
@@ -230,150 +236,9 @@ int dev_alloc(rj_handle h, T** p, uint64_t count) {
 }
 
 void free_map(MapState& m) {
-  (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.ccode); (void) hipFree(m.left); (void) hipFree(m.right);
+  (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.ccode); (void) hipFree(m.left); (void) hipFree(m.right); (void) hipFree(m.edge_begin);
   (void) hipFree(m.piece_begin); (void) hipFree(m.piece_len); (void) hipFree(m.run_first);
   m = MapState();
-}
-
-// Chain-run leaves (the reference's RT grouping: src/rt/primitive.h:120-260, rt_lsi_custom.cu:31-44):
-// a leaf = a run of <= 64 consecutive edges of ONE POLYLINE.  A CDB chain ends at every junction, so a polyline is
-// stitched through the junctions first: at every shared end point the incident chains are paired by straightest
-// continuation (smallest cosine between their directions there, at most 120 degrees of turn), the pairs are followed
-// into paths -- a lattice row, a river, a county line -- and every path is cut into ceil(len / 64) near-equal runs.
-// A run is then a list of pieces (eid ranges of the chains it crosses; a chain walked backwards contributes the same
-// eids, the order inside a leaf is free).  Chains that merely follow each other in the FILE are never joined: a leaf of
-// unrelated chains has a box as large as their distance (measured: PIP 1.9 -> 8.2 ms on the WaterBodies stand-in at
-// its row ends, 4 orders of magnitude on the gaussian polygons, whose file order is random).
-// Host code, once per uploaded map (the first rj_build_lbvh that wants it): O(chains) with a hash of the end points.
-struct RunSet {
-  std::vector<uint32_t> piece_begin, piece_len, run_first;  // run_first[nruns + 1]
-};
-
-RunSet stitch_runs(const int64_t* xy, const std::vector<uint32_t>& eb, uint64_t cap_edges) {
-  RunSet R;
-  const size_t nc = eb.empty() ? 0 : eb.size() - 1;
-  constexpr uint32_t kNone = 0xFFFFFFFFu;
-  // incidence i = 2 c + end (0: the chain's first point, 1: its last); the point indices of chain c: first = eb[c] + c
-  auto first_pt = [&](size_t c) { return (uint64_t) eb[c] + c; };
-  auto last_pt = [&](size_t c) { return (uint64_t) eb[c + 1] + c; };
-  // The end points and the directions of the chains AT their ends, gathered once in chain order (the passes below
-  // touch them at random)
-  std::vector<int64_t> ex(2 * nc), ey(2 * nc);
-  std::vector<float> dirx(2 * nc), diry(2 * nc);
-  std::vector<uint64_t> hsh(2 * nc);
-  for (size_t c = 0; c < nc; c++) {
-    const uint64_t p0 = first_pt(c), p1 = last_pt(c);
-    for (int end = 0; end < 2; end++) {
-      const uint32_t i = (uint32_t) (2 * c + end);
-      const uint64_t p = end ? p1 : p0, q = end ? p1 - 1 : p0 + 1;  // q: the vertex next to this end, inside the chain
-      ex[i] = xy[2 * p]; ey[i] = xy[2 * p + 1];
-      const double vx = (double) (xy[2 * q] - ex[i]), vy = (double) (xy[2 * q + 1] - ey[i]);
-      const double n = std::sqrt(vx * vx + vy * vy);
-      dirx[i] = n > 0 ? (float) (vx / n) : 0.0f;
-      diry[i] = n > 0 ? (float) (vy / n) : 0.0f;
-      uint64_t v = ((uint64_t) ex[i] * 0x9E3779B97F4A7C15ull) ^ (((uint64_t) ey[i] + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full);
-      hsh[i] = v ^ (v >> 29);
-    }
-  }
-  // 1 + 2, in parallel over hash partitions (a node lives in exactly one): an open-addressing table of the end points
-  // -> that node's incidence list, then the incidences of every node paired by straightest continuation
-  std::vector<uint32_t> partner(2 * nc, kNone);
-  unsigned nthreads = std::thread::hardware_concurrency();
-  nthreads = nthreads < 1 ? 1 : (nthreads > 16 ? 16 : nthreads);
-  if (nc < 50000) nthreads = 1;
-  auto part = [&](unsigned t) {
-    size_t cap = 16;
-    while (cap < (4 * nc) / nthreads + 16) cap <<= 1;
-    std::vector<uint32_t> slot_head(cap, kNone), inc_next(2 * nc, kNone);
-    for (uint32_t i = 0; i < 2 * nc; i++) {
-      if ((hsh[i] >> 40) % nthreads != t) continue;
-      size_t sl = (size_t) hsh[i] & (cap - 1);
-      for (;;) {
-        const uint32_t head = slot_head[sl];
-        if (head == kNone) { slot_head[sl] = i; break; }
-        if (ex[head] == ex[i] && ey[head] == ey[i]) { inc_next[i] = head; slot_head[sl] = i; break; }
-        sl = (sl + 1) & (cap - 1);
-      }
-    }
-    uint32_t at[16];
-    for (size_t sl = 0; sl < cap; sl++) {
-      if (slot_head[sl] == kNone) continue;
-      int n = 0;
-      bool hub = false;
-      for (uint32_t i = slot_head[sl]; i != kNone; i = inc_next[i]) {
-        if (ex[i] == ex[i ^ 1] && ey[i] == ey[i ^ 1]) continue;  // a closed chain (a polygon): it starts and ends here, nothing to continue
-        if (dirx[i] == 0.0f && diry[i] == 0.0f) continue;
-        if (n == 16) { hub = true; break; }                      // a hub of more than 16 chains: leave them be
-        at[n++] = i;
-      }
-      if (hub || n < 2) continue;
-      bool used[16] = {false};
-      for (;;) {
-        float best = -0.5f;  // cos of the angle between the two directions AWAY from the node: -1 = straight on
-        int bi = -1, bj = -1;
-        for (int u = 0; u < n; u++)
-          for (int v = u + 1; v < n; v++) {
-            if (used[u] || used[v] || (at[u] >> 1) == (at[v] >> 1)) continue;
-            const float d = dirx[at[u]] * dirx[at[v]] + diry[at[u]] * diry[at[v]];
-            if (d < best) { best = d; bi = u; bj = v; }
-          }
-        if (bi < 0) break;
-        used[bi] = used[bj] = true;
-        partner[at[bi]] = at[bj];
-        partner[at[bj]] = at[bi];
-      }
-    }
-  };
-  if (nthreads == 1) {
-    part(0);
-  } else {
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(part, t);
-    for (auto& th : pool) th.join();
-  }
-  // 3. follow the pairs into paths, cut every path into near-equal runs of <= 64 edges
-  std::vector<bool> visited(nc, false);
-  std::vector<uint32_t> path;  // incidences through which the path ENTERS its chains
-  R.run_first.push_back(0);
-  auto emit = [&]() {
-    uint64_t total = 0;
-    for (uint32_t i : path) total += eb[(i >> 1) + 1] - eb[i >> 1];
-    if (!total) return;
-    const uint64_t k = (total + cap_edges - 1) / cap_edges;
-    uint64_t run = 0, done = 0, run_end = total / k;  // run `run` covers path positions [total run / k, total (run + 1) / k)
-    for (uint32_t i : path) {
-      const size_t c = i >> 1;
-      const uint32_t len = eb[c + 1] - eb[c];
-      uint32_t used_c = 0;  // edges of this chain already handed out, counted from the end the path entered by
-      while (used_c < len) {
-        const uint32_t take = (uint32_t) std::min<uint64_t>(len - used_c, run_end - done);
-        // entered at its first point: the next `take` eids from the front; at its last point: from the back
-        R.piece_begin.push_back((i & 1) ? eb[c + 1] - used_c - take : eb[c] + used_c);
-        R.piece_len.push_back(take);
-        used_c += take;
-        done += take;
-        if (done == run_end && done < total) {
-          R.run_first.push_back((uint32_t) R.piece_begin.size());
-          run++;
-          run_end = total * (run + 1) / k;
-        }
-      }
-    }
-    R.run_first.push_back((uint32_t) R.piece_begin.size());
-  };
-  auto walk = [&](uint32_t enter) {
-    path.clear();
-    for (uint32_t i = enter; i != kNone && !visited[i >> 1]; i = partner[i ^ 1]) {
-      visited[i >> 1] = true;
-      path.push_back(i);
-    }
-    emit();
-  };
-  for (uint32_t i = 0; i < 2 * nc; i++)  // paths start at an end that continues nothing
-    if (partner[i] == kNone && !visited[i >> 1] && eb[(i >> 1) + 1] > eb[i >> 1]) walk(i);
-  for (uint32_t i = 0; i < 2 * nc; i += 2)  // what is left are closed loops of paired chains
-    if (!visited[i >> 1] && eb[(i >> 1) + 1] > eb[i >> 1]) walk(i);
-  return R;
 }
 
 void free_grid(GridState& g) {
@@ -649,6 +514,10 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "leaf_order")) *value = h->leaf_order;
   else if (!strcmp(name, "leaf_order_used0") || !strcmp(name, "leaf_order_used1")) *value = h->bvh[name[15] - '0'].leaf_order;  // what the index of map 0 / 1 was built with
   else if (!strcmp(name, "leaf_slots0") || !strcmp(name, "leaf_slots1")) *value = (int64_t) h->bvh[name[10] - '0'].n0p;  // slots of the index of map 0 / 1 (64 per leaf, padding included)
+  else if (!strcmp(name, "leaf_runs0") || !strcmp(name, "leaf_runs1")) *value = h->map[name[9] - '0'].runs_cut ? (int64_t) h->map[name[9] - '0'].nruns : -1;  // polyline runs cut for map 0 / 1 (-1: none cut)
+  else if (!strcmp(name, "stitch_rounds")) *value = h->stitch_stats[0];      // the last run cutting: pointer-jumping rounds that had work
+  else if (!strcmp(name, "stitch_loop_ends")) *value = h->stitch_stats[1];   // ... chain ends on closed loops of paired chains
+  else if (!strcmp(name, "debug_run_cap")) *value = h->debug_run_cap;
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
   else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
@@ -672,6 +541,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "leaf_order")) {
     if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
     h->leaf_order = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "debug_run_cap")) {  // (experiments: edges per polyline run of the NEXT first build of a map; 0 = by the mean chain length)
+    if (value != 0 && (value < 2 || value > 64)) return fail(h, RJ_E_INVALID, "debug_run_cap: 0 or 2..64");
+    h->debug_run_cap = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "lsi_segments")) {
@@ -760,7 +634,6 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   std::vector<uint32_t> eb(nc + 1), l32(nc), r32(nc);
   for (uint64_t c = 0; c <= nc; c++) eb[c] = nc ? (uint32_t) (row_index[c] - c) : 0;
   for (uint64_t c = 0; c < nc; c++) { l32[c] = (uint32_t) left[c]; r32[c] = (uint32_t) right[c]; }  // map.h:45
-  uint32_t* d_eb = nullptr;
   int rc = RJ_OK;
   if (!rc) rc = dev_alloc(h, &m.pts, 2 * np + 2);
   if (!rc) rc = dev_alloc(h, &m.seg, m.ne);
@@ -768,23 +641,21 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (!rc) rc = dev_alloc(h, &m.ccode, m.ne);
   if (!rc) rc = dev_alloc(h, &m.left, nc);
   if (!rc) rc = dev_alloc(h, &m.right, nc);
-  if (!rc) rc = dev_alloc(h, &d_eb, nc + 1);
+  if (!rc) rc = dev_alloc(h, &m.edge_begin, nc + 1);
   hipError_t e = hipSuccess;
   if (!rc) {
     if (np) e = hipMemcpyAsync(m.pts, xy, 16 * np, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess && nc) e = hipMemcpyAsync(d_eb, eb.data(), 4 * (nc + 1), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && nc) e = hipMemcpyAsync(m.edge_begin, eb.data(), 4 * (nc + 1), hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && nc) e = hipMemcpyAsync(m.left, l32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess && nc) e = hipMemcpyAsync(m.right, r32.data(), 4 * nc, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, d_eb, (uint32_t) nc, m.ne, m.seg, m.edge_chain, m.ccode);
-    // whatever was enqueued reads the host vectors and d_eb: drain the stream before they go away
+    if (e == hipSuccess) e = launch_build_segs(h->stream, m.pts, m.edge_begin, (uint32_t) nc, m.ne, m.seg, m.edge_chain, m.ccode);
+    // whatever was enqueued reads the host vectors: drain the stream before they go away
     const hipError_t es = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = es;
   }
-  (void) hipFree(d_eb);
   if (rc || e != hipSuccess) free_map(m);  // no half-uploaded map
   if (rc) return rc;
   RJ_HIP(h, e);
-  m.h_edge_begin = std::move(eb);
   m.present = true;
   return RJ_OK;
 }
@@ -835,6 +706,20 @@ int rj_map_points_dev(rj_handle h, int map_id, const int64_t** pts_dev) {
   return RJ_OK;
 }
 
+int rj_map_runs(rj_handle h, int map_id, uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first, uint64_t* nruns, uint64_t* npieces) {
+  RJ_CHECK_H(h);
+  if (map_id < 0 || map_id > 1 || !h->map[map_id].present) return fail(h, RJ_E_INVALID, "rj_map_runs: map not uploaded");
+  const MapState& m = h->map[map_id];
+  if (!m.runs_cut) return fail(h, RJ_E_INVALID, "rj_map_runs: no runs cut for map %d (rj_build_lbvh with \"leaf_order\" 1 first)", map_id);
+  if (nruns) *nruns = m.nruns;
+  if (npieces) *npieces = m.npieces;
+  if (int r = set_device(h)) return r;
+  if (piece_begin) RJ_HIP(h, hipMemcpy(piece_begin, m.piece_begin, 4 * m.npieces, hipMemcpyDeviceToHost));
+  if (piece_len) RJ_HIP(h, hipMemcpy(piece_len, m.piece_len, 4 * m.npieces, hipMemcpyDeviceToHost));
+  if (run_first) RJ_HIP(h, hipMemcpy(run_first, m.run_first, 4 * (m.nruns + 1), hipMemcpyDeviceToHost));
+  return RJ_OK;
+}
+
 // Sort scratch ((u64 key, u32 value) in/out + rocPRIM temp) shared by the index build and the
 // query re-ordering; it only grows and stays with the handle, so a rebuild or a repeated query
 // does not pay hipMalloc again (24 B per item + temp; 2.4 GB for the 67 M-segment map).
@@ -867,31 +752,45 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   RJ_HIP(h, join_aux(h));
   const MapState& m = h->map[base_map_id];
   BvhState& b = h->bvh[base_map_id];
-  // "leaf_order" 1: the leaves are runs of consecutive eids, cut on the host from the chain layout
-  if (h->leaf_order == 1 && m.ne && !h->map[base_map_id].runs_cut) {
-    // the first index of this map that wants polyline runs: fetch the points, stitch and cut on the host, keep the
-    // pieces on the device (a later rebuild only sorts the runs)
+  // RJ_T_BUILD spans everything this call does, the first time too: cutting the runs, allocating, sorting, the leaves
+  // (the reference's "Build Index", run_query.cu, runs once per map: that is the build to quote)
+  h->ev_valid[RJ_T_BUILD_RUNS] = false;
+  tic(h, RJ_T_BUILD);
+  // "leaf_order" 1: the leaves are polyline runs -- chains stitched through the junctions and cut into runs of <= 64
+  // consecutive edges (rj_stitch.h; the reference's RT grouping, src/rt/primitive.h:120-260) -- cut ON THE DEVICE the
+  // first time an index of this map wants them and kept (a later rebuild only sorts the runs).
+  if (h->leaf_order == 1 && m.ne && m.nc < (1ull << 30) && !m.runs_cut) {
     MapState& mm = h->map[base_map_id];
-    std::vector<int64_t> xy(2 * mm.np);
-    RJ_HIP(h, hipMemcpy(xy.data(), mm.pts, 16 * mm.np, hipMemcpyDeviceToHost));
     // How long a run may be.  A full leaf (64 edges) is right where chains are long: the strip is a piece of one smooth
     // line.  A polyline stitched from many SHORT chains wiggles through a junction every few edges, its strip is fat,
     // and where it runs steeply all of its edges overlap in x -- the in-leaf scans (x-sorted slots) then test every
     // slot.  Half-full leaves of 32 edges measured better there on BOTH kernels (WaterBodies stand-in, 10-edge chains:
     // k_lsi 1.29 vs 1.49 ms with 64, 1.37 Hilbert; PIP 1.75 vs 1.88 / 1.88) and worse where chains are long (USCounty:
     // PIP 0.87 vs 0.74): the cap follows the mean chain length.
-    uint64_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
-    if (const char* e = getenv("RJ_RUN_CAP")) { const int v = atoi(e); if (v >= 8 && v <= 64) cap_edges = (uint64_t) v; }  // (experiments)
-    const RunSet R = stitch_runs(xy.data(), mm.h_edge_begin, cap_edges);
+    uint32_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
+    if (h->debug_run_cap) cap_edges = (uint32_t) h->debug_run_cap;
+    uint64_t max_pieces = 0, max_runs = 0;
+    stitch_output_bounds(mm.nc, mm.ne, cap_edges, &max_pieces, &max_runs);
+    tic(h, RJ_T_BUILD_RUNS);
+    int rc = dev_alloc(h, &mm.piece_begin, max_pieces);
+    if (!rc) rc = dev_alloc(h, &mm.piece_len, max_pieces);
+    if (!rc) rc = dev_alloc(h, &mm.run_first, max_runs + 1);
+    hipError_t e = hipSuccess;
+    uint64_t nruns_cut = 0, npieces_cut = 0;
+    if (!rc) e = stitch_runs_device(h->stream, mm.pts, mm.edge_begin, mm.nc, mm.ne, cap_edges, mm.piece_begin, mm.piece_len, mm.run_first,
+                                    &nruns_cut, &npieces_cut, h->stitch_stats);
+    if (rc || e != hipSuccess) {  // no half-cut map: a retried build starts over
+      (void) hipFree(mm.piece_begin); (void) hipFree(mm.piece_len); (void) hipFree(mm.run_first);
+      mm.piece_begin = mm.piece_len = mm.run_first = nullptr;
+      mm.nruns = mm.npieces = 0;
+      if (rc) return rc;
+      RJ_HIP(h, e);
+    }
+    toc(h, RJ_T_BUILD_RUNS);
+    mm.nruns = nruns_cut;
+    mm.npieces = npieces_cut;
+    mm.run_cap = cap_edges;
     mm.runs_cut = true;
-    mm.nruns = R.run_first.size() - 1;
-    mm.npieces = R.piece_begin.size();
-    if (int r = dev_alloc(h, &mm.piece_begin, mm.npieces)) return r;
-    if (int r = dev_alloc(h, &mm.piece_len, mm.npieces)) return r;
-    if (int r = dev_alloc(h, &mm.run_first, mm.nruns + 1)) return r;
-    RJ_HIP(h, hipMemcpy(mm.piece_begin, R.piece_begin.data(), 4 * mm.npieces, hipMemcpyHostToDevice));
-    RJ_HIP(h, hipMemcpy(mm.piece_len, R.piece_len.data(), 4 * mm.npieces, hipMemcpyHostToDevice));
-    RJ_HIP(h, hipMemcpy(mm.run_first, R.run_first.data(), 4 * (mm.nruns + 1), hipMemcpyHostToDevice));
   }
   // (a map of short polylines -- polygons of a few edges that touch nothing -- would leave its leaves mostly empty:
   //  above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
@@ -902,7 +801,6 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   if (!reuse) free_bvh(b);
   b.built = false;
   b.leaf_order = nruns ? 1 : 0;
-  tic(h, RJ_T_BUILD);
   b.n0 = m.ne;
   b.n0p = n0p_new;
   // level sizes: level l has ceil(n_{l-1}/64) nodes; top = first level with <= 64 nodes
@@ -1075,6 +973,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
     if (order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
     h->co_mode = pairable ? (h->pip_concurrent == 2 ? (h->co_choice >= 0 ? h->co_choice : 0) : 1) : 0;
     h->cap_lsi = true;
+    if (qe > qb) h->cap_kinds |= 1;
   } else {
     h->co_mode = pairable ? (h->pip_concurrent == 2 ? co_pick(h, qe - qb) : 1) : 0;
   }
@@ -1161,6 +1060,7 @@ static hipError_t lsi_points_on_stream(rj_handle h, const uint32_t* pairs_dev, u
   hipError_t e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, n_dev, out, list,
                                    h->d_counter + kSlowCountWord + f, h->d_counter + kSlowCountWord + (1 - f), h->d_rest + 2);
   if (list && !h->capturing) h->flip_slow = 1 - f;
+  if (list && h->capturing) h->cap_kinds |= 32;
   h->last_points_split = list ? 1 : 0;
   return e;
 }
@@ -1356,6 +1256,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
     toc(h, RJ_T_PIP_WALK, st);
     if (!h->capturing) h->flip_walk[si] = 1 - wflip;
+    else h->cap_kinds |= (8 << si) | (2 << si);
     // second pass: the exact predicate over the candidate lists, and -- the kernel's first blocks -- k_pip's traversal
     // over the points whose list overflowed; that part's grid follows the last count seen for this query size
     // (the list is appended group by group all over the map: the fewer points it holds, the less a wave's points have
@@ -1382,6 +1283,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   } else if (n) {
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
     if (!h->capturing) h->flip_pip[aux ? 1 : 0] = 1 - pflip;
+    else h->cap_kinds |= 2 << (aux ? 1 : 0);
   }
   toc(h, RJ_T_PIP_KERNEL, st);
   if (aux) h->aux_pending = true;
@@ -1721,6 +1623,7 @@ int rj_graph_begin(rj_handle h, int id) {
   h->capturing = true;
   h->cap_aux = two && e == hipSuccess;
   h->cap_lsi = false;
+  h->cap_kinds = 0;
   // a replayed step cannot alternate between two counter sets (its arguments are frozen): it uses set 0 of every kind
   // and clears them first (the kernels still clear set 1, which nothing reads); each stream clears what its kernels use
   if (e == hipSuccess) e = hipMemsetAsync(h->d_counter, 0, 16, h->stream);                                // LSI result counts
@@ -1770,6 +1673,7 @@ int rj_graph_end(rj_handle h) {
   h->cap_aux = false;
   h->graph[h->cap_id] = g;
   h->graph_aux[h->cap_id] = ga;
+  h->graph_kinds[h->cap_id] = h->cap_kinds;
   RJ_HIP(h, hipGraphInstantiate(&h->graph_exec[h->cap_id], g, nullptr, nullptr, 0));
   if (ga) RJ_HIP(h, hipGraphInstantiate(&h->graph_exec_aux[h->cap_id], ga, nullptr, nullptr, 0));
   return RJ_OK;
@@ -1780,6 +1684,15 @@ int rj_graph_launch(rj_handle h, int id) {
   if (id < 0 || id >= rj_handle_s::kGraphs || !h->graph_exec[id] || h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_launch: no captured step %d", id);
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipGraphLaunch(h->graph_exec[id], h->stream));
+  // the replay runs on counter set 0 of every kind it holds and leaves set 1 cleared: a plain launch that follows must
+  // use set 1 (it would find set 0 exhausted, do nothing and report the replay's count)
+  const int kinds = h->graph_kinds[id];
+  if (kinds & 1) { h->flip_lsi = 1; h->count_word = 0; }
+  for (int k = 0; k < 2; k++) {
+    if (kinds & (2 << k)) h->flip_pip[k] = 1;
+    if (kinds & (8 << k)) h->flip_walk[k] = 1;
+  }
+  if (kinds & 32) h->flip_slow = 1;
   if (h->graph_exec_aux[id]) {
     RJ_HIP(h, hipGraphLaunch(h->graph_exec_aux[id], h->aux_stream));
     h->aux_pending = true;  // (rj_sync / rj_graph_lsi_count + rj_sync join it)

@@ -116,6 +116,12 @@ hipError_t launch_xsect_gather(hipStream_t st, const XsectRec* in, const uint32_
 hipError_t launch_xsect_order_runs(hipStream_t st, XsectRec* rec, uint64_t n, int im, const Seg* seg_im, int64_t* midpts);
 hipError_t launch_xsect_set_mid(hipStream_t st, XsectRec* rec, uint64_t n, int im, const int32_t* face);
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
+// Polyline runs of a map, cut on the device (rj_stitch.hip): pieces and runs into caller-owned arrays sized by
+// stitch_output_bounds; two host syncs (closed loops left? -- the totals), no read-back of the map.
+void stitch_output_bounds(uint64_t nc, uint64_t ne, uint32_t cap, uint64_t* max_pieces, uint64_t* max_runs);
+hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin, uint64_t nc, uint64_t ne, uint32_t cap,
+                              uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first, uint64_t* nruns, uint64_t* npieces,
+                              uint32_t* stats /* [3] nullable: ranking rounds, incidences on closed loops, rounds of the second ranking */);
 hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* piece_begin, const uint32_t* piece_len, const uint32_t* run_first,
                            uint64_t nruns, MortonKey* keys, uint32_t* vals);
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,

@@ -524,6 +524,29 @@ def test_captured_step_replays_the_same_results(oracle):
                 got = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
                 assert np.array_equal(oracle.sort_pairs(got.copy()), want_pairs)
             assert h.last_ms(_capi.RJ_T_PIP_KERNEL) > 0 and h.last_ms(_capi.RJ_T_LSI_KERNEL) > 0
+            # a plain query right behind a replay (the replay used counter set 0 of every kind and left set 1 cleared):
+            # other buffers, another range -- it must do its own work, not report the replay's
+            half_e, half_p = q.n_edges // 2, q.n_points // 3
+            pairs2, xs2 = h.alloc(8 * cap), h.alloc(48 * cap)
+            closest2, faces2 = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+            closest2.from_host(np.full(q.n_points, 7, dtype=np.uint32))
+            h.lsi_query_async(0, 1, 0, half_e, cap, pairs2)
+            h.pip_query(0, 1, None, 0, half_p, closest2, faces2, sync=False)
+            h.lsi_points_async(pairs2, cap, xs2)
+            n2 = h.lsi_query_finish(cap); h.sync()
+            want_half = want_pairs[want_pairs[:, 1] < half_e]
+            assert n2 == len(want_half), (conc, n2, len(want_half))
+            assert np.array_equal(oracle.sort_pairs(pairs2.to_host(np.uint32, 2 * n2).reshape(-1, 2).copy()), want_half)
+            assert np.array_equal(closest2.to_host(np.uint32)[:half_p], want_eids[:half_p])
+            assert np.array_equal(faces2.to_host(np.int32)[:half_p], m0.face_ids(want_eids[:half_p]))
+            got2 = xs2.to_host(_capi.XSECT_DTYPE, n2)
+            ref2 = oracle.lsi_points(m0, m1, np.ascontiguousarray(got2["eid"]))
+            assert np.array_equal(got2["x_num"], ref2["x_num"]) and np.array_equal(got2["y_num"], ref2["y_num"])
+            # ... and a replay behind the plain query still equals the oracle
+            h.graph_launch(conc)
+            assert h.graph_lsi_count(cap) == len(want_pairs)
+            h.sync()
+            assert np.array_equal(closest.to_host(np.uint32), want_eids)
         with pytest.raises(_capi.RayJoinError):
             h.graph_launch(3)  # never captured
     finally:
