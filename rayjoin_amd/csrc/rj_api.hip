@@ -417,6 +417,10 @@ int rj_create(int device_id, rj_handle* out) {
   ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+  // load every code object of the library now (a kernel's first launch loads its file's code object: milliseconds
+  // that would otherwise land in the first upload, the first index build and the first query)
+  ok = ok && warm_query_kernels(h->stream) == hipSuccess && warm_grid_kernels(h->stream) == hipSuccess &&
+       warm_stitch_kernels(h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
   if (!ok) { delete h; return RJ_E_HIP; }
   *out = h;
   return RJ_OK;

@@ -206,6 +206,11 @@ hipError_t launch_grid_unpack(hipStream_t st, const uint64_t* keys, uint64_t n, 
   if (n) hipLaunchKernelGGL(k_grid_unpack, dim3(grid_blocks(n, 256, 8192)), dim3(256), 0, st, keys, n, eids);
   return hipGetLastError();
 }
+__global__ void k_grid_noop() {}
+hipError_t warm_grid_kernels(hipStream_t st) {  // (see warm_stitch_kernels)
+  hipLaunchKernelGGL(k_grid_noop, dim3(1), dim3(1), 0, st);
+  return hipGetLastError();
+}
 hipError_t scan_cell_counts(hipStream_t st, void* temp, size_t& temp_bytes, const uint32_t* counts, uint32_t* begin, uint64_t n) {
   return rocprim::exclusive_scan(temp, temp_bytes, counts, begin, 0u, (size_t) n, rocprim::plus<uint32_t>(), st);
 }

@@ -116,6 +116,11 @@ hipError_t launch_xsect_gather(hipStream_t st, const XsectRec* in, const uint32_
 hipError_t launch_xsect_order_runs(hipStream_t st, XsectRec* rec, uint64_t n, int im, const Seg* seg_im, int64_t* midpts);
 hipError_t launch_xsect_set_mid(hipStream_t st, XsectRec* rec, uint64_t n, int im, const int32_t* face);
 hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n);
+// One empty kernel per translation unit: the first launch from a file loads that file's code object (10-60 ms under a
+// profiler, ~15 ms without) -- rj_create launches these so that no upload, build or query pays it.
+hipError_t warm_query_kernels(hipStream_t st);
+hipError_t warm_grid_kernels(hipStream_t st);
+hipError_t warm_stitch_kernels(hipStream_t st);
 // Polyline runs of a map, cut on the device (rj_stitch.hip): pieces and runs into caller-owned arrays sized by
 // stitch_output_bounds; two host syncs (closed loops left? -- the totals), no read-back of the map.
 void stitch_output_bounds(uint64_t nc, uint64_t ne, uint32_t cap, uint64_t* max_pieces, uint64_t* max_runs);

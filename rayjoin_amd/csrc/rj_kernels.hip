@@ -1965,6 +1965,12 @@ __global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A, Pi
 // =============================================================================================
 // launch wrappers
 // =============================================================================================
+__global__ void k_noop() {}
+hipError_t warm_query_kernels(hipStream_t st) {  // (see warm_stitch_kernels)
+  hipLaunchKernelGGL(k_noop, dim3(1), dim3(1), 0, st);
+  return hipGetLastError();
+}
+
 static inline int grid_for(uint64_t work_items, int per_block, int max_blocks) {
   uint64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
