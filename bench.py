@@ -182,13 +182,15 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         # once the handle has settled on running the two sides beside each other, the PIP query -- the longer
         # side, on the handle's second stream -- is issued right behind the LSI query (8-10 us earlier)
         early = h.get_option("pip_schedule") in (1, 2)
+        # (the query points: the map's own vertices by range, or -- the reference's interface, pip.h:23 -- a caller-owned array)
+        qpts, qbeg = (state["caller_pts"], 0) if state.get("caller_pts") is not None else (None, p0)
         if early:
-            h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+            h.pip_query(0, 1, qpts, qbeg, p1 - p0, closest, faces, sync=False)
         h.lsi_points_async(pairs, cap, xsects)  # the records of this rank's hits (count read on the device)
         if world > 1:
             ex.begin(h)
         if not early:
-            h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+            h.pip_query(0, 1, qpts, qbeg, p1 - p0, closest, faces, sync=False)
         if world > 1:  # RCCL all-gather-v of the intersection queues (rank order, zero-copy views)
             state["pairs_all"], state["cnt_all"] = ex.finish()
             n = state["cnt_all"][rank]
@@ -326,6 +328,29 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         # every rank now holds every shard's queue: this rank's slice of the gathered buffer is its own result
         gathered_ok = bool(torch.equal(state["ids_all"][rank, :p1 - p0], closest[:p1 - p0]))
 
+    # The same steps with the PIP query handed a CALLER-OWNED point array (the reference's PIP::Query(Stream&, int,
+    # ArrayView<point_t>), src/app/pip.h:23; src/run_query.cu:346,441-443 passes a separate device vector): a copy of
+    # this rank's vertices.  After its first query the handle enqueues such a query without a host round trip and pairs
+    # it with the LSI query in flight like a map-owned range; the results must be the map-owned ones.
+    caller = None
+    if world == 1 and p1 > p0:
+        own = closest[:p1 - p0].clone()
+        cpts = torch.from_numpy(np.ascontiguousarray(query.pts[p0:p1])).to(dev)
+        state["caller_pts"] = cpts
+        for _ in range(3):   # (first sight: one estimate with a round trip; then the settled path)
+            step(False)
+        el_c = timed(steps)
+        same = bool(torch.equal(closest[:p1 - p0], own))
+        h.pip_query(0, 1, cpts, 0, p1 - p0, closest, faces)
+        pip_caller_ms = h.last_ms(_capi.RJ_T_PIP_KERNEL)
+        caller = {"ms_per_step": round(el_c * 1e3 / steps, 4), "ms_per_step_median": round(float(np.median(state["step_ms"])), 4),
+                  "vs_map_owned": round(el_c / elapsed, 4), "pip_query_ms_alone": round(pip_caller_ms, 4),
+                  "re_ordered": bool(h.get_option("query_last_ordered")), "equals_map_owned_results": same,
+                  "pip_schedule": h.get_option("pip_schedule")}
+        state["caller_pts"] = None
+        del cpts
+        step(False)  # (back on the map-owned path for what follows)
+
     # phase split (synchronous calls, wall clock), one extra untimed pass
     t0 = time.perf_counter(); h.lsi_query(0, 1, e0, e1, cap, pairs); t_lsi_wall = time.perf_counter() - t0
     t0 = time.perf_counter(); h.pip_query(0, 1, None, p0, p1 - p0, closest, faces); t_pip_wall = time.perf_counter() - t0
@@ -444,6 +469,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             "lsi_points_ms": round(float(np.mean(pts_ms)), 4), "result_digest": result_digest,
             "intersections": n_x, "build_index_ms": round(first_build_ms, 3), "build_index_wall_ms": round(first_build_wall_ms, 3),
             "build_index_runs_ms": round(build_runs_ms, 3), "rebuild_index_ms": round(build_ms, 3),
+            "pip_caller_array": caller,
             "index_leaves": "polyline runs" if h.get_option("leaf_order_used0") == 1 else "Hilbert neighbours",
             "host_ms": {"generate": round(t_gen * 1e3, 1), "upload_and_segment_build": round(t_upload * 1e3, 1)},
             "roofline": roof[dom], "roofline_other": roof["pip" if dom == "lsi" else "lsi"],

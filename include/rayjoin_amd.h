@@ -154,6 +154,15 @@ int rj_pip_query(rj_handle h, int base_map_id, int query_map_id, const int64_t* 
 int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
                        uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev,
                        int32_t* face_id_dev);
+/* Caller-owned point arrays (pts_dev != NULL -- the reference's PIP::Query(Stream&, int, ArrayView<point_t>),
+ * src/app/pip.h:23, handed a separate device vector by src/run_query.cu:346,441-443): the handle remembers, per
+ * (pointer, n), whether the array needs re-ordering along the Morton curve and the permutation if so.  The first
+ * query over an array pays one host round trip for the estimate; every later one is enqueued without any
+ * synchronisation, pairs with an LSI query in flight exactly like a map-owned range, and refreshes the estimate
+ * with a one-block kernel behind its own kernels, so contents that change are followed one query late.  None of
+ * it can affect results (any permutation of [0, n) is a valid processing order).  rj_invalidate forgets what was
+ * learned, e.g. before a buffer is reused for unrelated points. */
+int rj_invalidate(rj_handle h);
 
 /* ---- multi-GPU: RCCL over xGMI ---------------------------------------------------------- */
 /* ---- -mode=grid on the device (the reference's third index, for the grid / lbvh / rt comparison)

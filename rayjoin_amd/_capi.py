@@ -34,6 +34,7 @@ SYMBOLS = {
     "rj_map_num_edges": (_int, [_vp, _int, C.POINTER(_u64)]),
     "rj_map_num_points": (_int, [_vp, _int, C.POINTER(_u64)]),
     "rj_map_points_dev": (_int, [_vp, _int, C.POINTER(_vp)]),
+    "rj_invalidate": (_int, [_vp]),
     "rj_map_runs": (_int, [_vp, _int, _vp, _vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "rj_build_lbvh": (_int, [_vp, _int]),
     "rj_lsi_query": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp, C.POINTER(_u64)]),
@@ -254,6 +255,9 @@ class Handle:
         p = _vp()
         self._check(self.L.rj_map_points_dev(self.h, map_id, C.byref(p)))
         return p.value
+
+    def invalidate(self):
+        self._check(self.L.rj_invalidate(self.h))
 
     def map_runs(self, map_id):
         """-> (piece_begin, piece_len, run_first) of the polyline runs cut for this map"""

@@ -183,6 +183,30 @@ struct rj_handle_s {
   // ... and the Morton permutation of such a set, kept until the map is uploaded again: repeated
   // queries over the same immutable edges / vertices sort once (an index on the query side)
   struct OrdCache { uint32_t* perm = nullptr; uint64_t cap = 0, begin = 0, n = 0; bool valid = false; } ordc[2][2];
+  // Caller-owned point arrays (rj_pip_query* with pts_dev, the reference's PIP::Query(Stream&, int, ArrayView<point_t>),
+  // src/app/pip.h:23): what the handle has learned about the array at (pointer, size).  The contents may change between
+  // queries, so nothing here is ever a correctness input -- a permutation of [0, n) stays one whatever the points are --
+  // only a choice of processing order: the first query over an array estimates its coherence with one host round trip
+  // (like the first-use allocations), every later one reads the estimate a one-block kernel behind an earlier query's
+  // kernels left in mapped host memory (k_group_extent_tail, measured through the permutation in use): no
+  // synchronisation between rj_pip_query_async and its kernels, the query pairs with an LSI query in flight like a
+  // map-owned one, and an array whose contents turned incoherent is re-sorted by the query after the one that saw it.
+  struct CallerSet {
+    const void* p = nullptr;
+    uint64_t n = 0;
+    bool valid = false, has_perm = false, fresh_perm = false;
+    uint32_t* perm = nullptr;
+    uint64_t perm_cap = 0;
+    unsigned long long sorted_extent = 0;  // mean group extent right after the last sort (what "still sorted" looks like)
+    uint64_t queries = 0, stamp = 0;
+  };
+  static constexpr int kCallerSets = 4;
+  CallerSet caller[kCallerSets];
+  unsigned long long* h_est = nullptr;  // mapped host words, one per set: mean group extent + 1 of the last estimate (0: none yet)
+  unsigned long long* d_est = nullptr;
+  uint64_t caller_clock = 0;
+  int cur_caller = -1;                  // the set of the query being issued (-1: map-owned or too small to matter)
+  const uint32_t* cur_order = nullptr;
   // grow-only scratch of the query-ordering pass
   uint64_t ord_cap = 0;
   MortonKey *ord_kin = nullptr, *ord_kout = nullptr;
@@ -401,11 +425,14 @@ int rj_create(int device_id, rj_handle* out) {
             hipHostMalloc((void**) &h->h_fault, 64, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**) &h->d_fault, h->h_fault, 0) == hipSuccess &&
             hipHostMalloc((void**) &h->h_rest, 64, hipHostMallocMapped) == hipSuccess &&
-            hipHostGetDevicePointer((void**) &h->d_rest, h->h_rest, 0) == hipSuccess;
+            hipHostGetDevicePointer((void**) &h->d_rest, h->h_rest, 0) == hipSuccess &&
+            hipHostMalloc((void**) &h->h_est, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**) &h->d_est, h->h_est, 0) == hipSuccess;
   if (ok) {
     h->h_fault[0] = h->h_fault[1] = 0;
     h->h_rest[0] = h->h_rest[1] = ~0ull;  // (no finished two-pass query yet)
     h->h_rest[2] = ~0ull;                 // (... and no records produced yet: k_lsi_points' pair count)
+    for (int k = 0; k < rj_handle_s::kCallerSets; k++) h->h_est[k] = 0;
     ok = hipMemset(h->d_counter, 0, kCounterBytes) == hipSuccess;
     for (size_t blk : {kSchedLsi, kSchedLsi + kSchedBlockWords, kSchedPipMain, kSchedPipMain + kSchedBlockWords, kSchedPipAux,
                        kSchedPipAux + kSchedBlockWords, kSchedWalkMain, kSchedWalkMain + kSchedBlockWords, kSchedWalkAux,
@@ -435,6 +462,8 @@ int rj_destroy(rj_handle h) {
   for (int k = 0; k < 2; k++) for (int i = 0; i < 2; i++) (void) hipFree(h->ordc[k][i].perm);
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
   (void) hipFree(h->slow_list);
+  (void) hipHostFree(h->h_est);
+  for (int k = 0; k < rj_handle_s::kCallerSets; k++) (void) hipFree(h->caller[k].perm);
   (void) hipHostFree(h->h_rest); (void) hipFree(h->rest[0]); (void) hipFree(h->rest[1]); (void) hipFree(h->todo[0]); (void) hipFree(h->todo[1]); (void) hipFree(h->todo_mask[0]); (void) hipFree(h->todo_mask[1]);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
@@ -486,6 +515,19 @@ int rj_sync(rj_handle h) {
 
 const char* rj_last_error_string(rj_handle h) { return h ? h->err.c_str() : "null handle"; }
 
+int rj_invalidate(rj_handle h) {
+  RJ_CHECK_H(h);
+  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_invalidate: a step is being captured");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipStreamSynchronize(h->stream));  // (estimates in flight write the sets' words)
+  RJ_HIP(h, join_aux(h));
+  for (int k = 0; k < rj_handle_s::kCallerSets; k++) {
+    h->caller[k].valid = h->caller[k].has_perm = false;
+    h->h_est[k] = 0;
+  }
+  return RJ_OK;
+}
+
 int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   RJ_CHECK_H(h);
   if (!name || !value) return fail(h, RJ_E_INVALID, "rj_get_option: null argument");
@@ -494,6 +536,7 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "group_lanes")) *value = h->group_lanes;
   else if (!strcmp(name, "max_blocks")) *value = h->max_blocks;
   else if (!strcmp(name, "query_order")) *value = h->query_order;
+  else if (!strcmp(name, "query_last_ordered")) *value = h->last_ordered ? 1 : 0;  // the last query ran through a Morton permutation of its queries
   else if (!strcmp(name, "pip_concurrent")) *value = h->pip_concurrent;
   else if (!strcmp(name, "pip_schedule")) *value = h->pip_concurrent == 2 ? h->co_choice : (h->pip_concurrent == 1 ? 1 : 0);
   else if (!strcmp(name, "pip_schedule_trials")) *value = h->co_trials;
@@ -879,6 +922,84 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   return RJ_OK;
 }
 
+// A caller-owned point array under "query_order" 1 (see rj_handle_s::CallerSet): which order to process it in, without a
+// host round trip except the first time the array (pointer, size) is seen.
+static int sort_query_points(rj_handle h, const int64_t* pts, uint64_t n) {  // -> h->ord_vout
+  if (int r = ensure_sort_scratch(h, n)) return r;
+  tic(h, RJ_T_ORDER);
+  RJ_HIP(h, launch_query_keys(h->stream, true, pts, nullptr, 0, n, h->ord_kin, h->ord_vin));
+  size_t tb = h->ord_temp_bytes;
+  RJ_HIP(h, sort_morton_pairs(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
+  toc(h, RJ_T_ORDER);
+  return RJ_OK;
+}
+static int order_caller_points(rj_handle h, const int64_t* pts, uint64_t n, const uint32_t** order_out) {
+  rj_handle_s::CallerSet* e = nullptr;
+  int slot = -1;
+  for (int k = 0; k < rj_handle_s::kCallerSets; k++)
+    if (h->caller[k].valid && h->caller[k].p == pts && h->caller[k].n == n) { e = &h->caller[k]; slot = k; }
+  bool incoherent = false;
+  if (!e) {
+    // first sight of this array: one estimate with a host round trip (a captured step cannot hold one)
+    if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its coherence estimate needs a host round trip)");
+    slot = 0;  // a free set, else the one used longest ago
+    for (int k = 0; k < rj_handle_s::kCallerSets; k++) {
+      if (!h->caller[k].valid) { slot = k; break; }
+      if (h->caller[k].stamp < h->caller[slot].stamp) slot = k;
+    }
+    e = &h->caller[slot];
+    // (an estimate still in flight for the set that goes away would land in the new set's word: drain first)
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    RJ_HIP(h, join_aux(h));
+    uint32_t* keep = e->perm;
+    const uint64_t keep_cap = e->perm_cap;
+    *e = rj_handle_s::CallerSet();
+    e->perm = keep; e->perm_cap = keep_cap;
+    e->p = pts; e->n = n; e->valid = true;
+    h->h_est[slot] = 0;
+    RJ_HIP(h, launch_group_extent_tail(h->stream, pts, nullptr, n, h->d_est + slot));
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    incoherent = h->h_est[slot] > kIncoherentExtent + 1;
+  } else {
+    const unsigned long long v = h->h_est[slot];  // whatever the last finished estimate said (through the permutation then in use)
+    if (v) {
+      if (e->has_perm) {
+        if (e->fresh_perm) { e->sorted_extent = v - 1; e->fresh_perm = false; }
+        // the order no longer fits the contents: much wider groups than right after the sort
+        incoherent = v - 1 > kIncoherentExtent && v - 1 > 2 * e->sorted_extent;
+      } else {
+        incoherent = v - 1 > kIncoherentExtent;
+      }
+    }
+  }
+  e->stamp = ++h->caller_clock;
+  e->queries++;
+  if (incoherent) {
+    if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
+    if (e->perm_cap < n) {
+      RJ_HIP(h, hipStreamSynchronize(h->stream));  // (the old permutation may be in use)
+      RJ_HIP(h, join_aux(h));
+      (void) hipFree(e->perm);
+      e->perm = nullptr; e->perm_cap = 0; e->has_perm = false;
+      RJ_HIP(h, hipMalloc((void**) &e->perm, n * sizeof(uint32_t)));
+      e->perm_cap = n;
+    }
+    if (int r = sort_query_points(h, pts, n)) return r;
+    RJ_HIP(h, hipMemcpyAsync(e->perm, h->ord_vout, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
+    e->has_perm = true;
+    e->fresh_perm = true;   // the next estimate says what "sorted" looks like for these contents
+    h->h_est[slot] = 0;     // (estimates of the old order say nothing about this one; one still in flight is overwritten behind this query)
+    e->queries = 1;
+  }
+  if (e->has_perm) {
+    *order_out = e->perm;
+    h->last_ordered = true;
+  }
+  h->cur_caller = slot;
+  h->cur_order = *order_out;
+  return RJ_OK;
+}
+
 // Decide whether the query set [begin, begin+n) needs re-ordering and, if so, produce the
 // Morton-sorted permutation (indices relative to `begin`) in h->ord_vout.
 static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
@@ -886,7 +1007,10 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
                                uint64_t key_begin) {
   *order_out = nullptr;
   h->last_ordered = false;
+  h->cur_caller = -1;
+  h->cur_order = nullptr;
   if (h->query_order == 0 || n <= 64) return RJ_OK;
+  if (points && owner_map < 0 && h->query_order == 1) return order_caller_points(h, pts, n, order_out);
   if (h->query_order == 1) {
     rj_handle_s::CohCache* cc = owner_map >= 0 ? &h->coh[points ? 1 : 0][owner_map] : nullptr;
     bool incoherent;
@@ -1290,6 +1414,12 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     else h->cap_kinds |= 2 << (aux ? 1 : 0);
   }
   toc(h, RJ_T_PIP_KERNEL, st);
+  // a caller-owned array: the estimate the next query over it will go by, behind this query's kernels on their stream
+  // (the first queries after a sort or a first sight, then every fourth: one block, a few microseconds)
+  if (h->cur_caller >= 0 && n && !h->capturing) {
+    const rj_handle_s::CallerSet& e = h->caller[h->cur_caller];
+    if (e.queries <= 2 || e.queries % 4 == 0) RJ_HIP(h, launch_group_extent_tail(st, pts, h->cur_order, n, h->d_est + h->cur_caller));
+  }
   if (aux) h->aux_pending = true;
   return RJ_OK;
 }

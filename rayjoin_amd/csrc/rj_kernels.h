@@ -140,6 +140,7 @@ hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_chi
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks, int segs_per_lane = 1, int* segs_used = nullptr);
 hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                                uint64_t n, unsigned long long* out2);
+hipError_t launch_group_extent_tail(hipStream_t st, const int64_t* pts, const uint32_t* order, uint64_t n, unsigned long long* out_mapped);
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                              uint64_t n, MortonKey* keys, uint32_t* vals);
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
