@@ -151,17 +151,23 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         max_pts = max(b - a for a, b in (rjd.shard_of(query, world, r)["points"] for r in range(world)))
     gather_pip = world > 1 and not args.no_gather_pip
     # (two result buffers: a step's PIP queue is gathered while the next step fills the other one)
-    closest2 = [torch.empty(max_pts, dtype=torch.int32, device=dev) for _ in range(2 if gather_pip else 1)]
+    # (two of every result buffer a later step would overwrite while something still reads it: a step's PIP queue is
+    #  gathered while the next step fills the other one, and the pipelined loop launches step k + 1 before it has
+    #  looked at step k's count)
+    closest2 = [torch.empty(max_pts, dtype=torch.int32, device=dev) for _ in range(2)]
     faces = torch.empty(max_pts, dtype=torch.int32, device=dev)
     xsects = torch.empty((cap, 6), dtype=torch.int64, device=dev)  # dev::Intersection<int64_t>, 48 B each
     if world > 1:
-        # count + pairs leave in one all-gather on a second stream, overlapped with the PIP kernels
-        ex = rjd.PairExchange(cap, dev, slot=max(4096, int(0.02 * cap)))
-        pairs = ex.pairs
-        pg = rjd.PointGather(max_pts, dev) if gather_pip else None
+        # count + pairs leave in ONE all-gather on the handle's communication stream, overlapped with the PIP kernels:
+        # rj_exchange_* of the C ABI (RCCL through the handle's communicators; gloo only in the one-GPU rehearsal)
+        ex = rjd.PairExchange(h, cap, dev, slot=max(4096, int(0.02 * cap)))
+        pairs2 = ex.pairs
+        pg = rjd.PointGather(h, max_pts, dev) if gather_pip else None
     else:
-        pairs = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        ex = None
+        pairs2 = [torch.empty((cap, 2), dtype=torch.int32, device=dev) for _ in range(2)]
         pg = None
+    pairs = pairs2[0]
 
     lsi_ms, pip_ms, walk_ms, pts_ms = [], [], [], []
     state = {"k": 0}
@@ -188,11 +194,11 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             h.pip_query(0, 1, qpts, qbeg, p1 - p0, closest, faces, sync=False)
         h.lsi_points_async(pairs, cap, xsects)  # the records of this rank's hits (count read on the device)
         if world > 1:
-            ex.begin(h)
+            ex.begin(0)
         if not early:
             h.pip_query(0, 1, qpts, qbeg, p1 - p0, closest, faces, sync=False)
         if world > 1:  # RCCL all-gather-v of the intersection queues (rank order, zero-copy views)
-            state["pairs_all"], state["cnt_all"] = ex.finish()
+            state["pairs_all"], state["cnt_all"] = ex.finish(0)
             n = state["cnt_all"][rank]
         else:
             t_enq = time.perf_counter()
@@ -214,6 +220,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             pg.begin(closest)
         state["n"] = n
         state["closest"] = closest
+        state["last_pairs"] = pairs
 
     def barrier():
         if pg is not None:
@@ -221,6 +228,65 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # The same step WITHOUT a host sync at its end: step j is enqueued into buffer set j % 2, and only then does the
+    # host look at step j - 1 -- its count (N = 1: rj_lsi_count_wait, an event) or the gathered heads of its exchange
+    # (N > 1: rj_exchange_pairs_finish, the communication stream) -- so the GPU never idles while the host wakes up;
+    # step j - 1's PIP queue is gathered behind step j's kernels.  Every step's results are complete and looked at
+    # inside the timed region (the closing barrier waits for the last).
+    def pipelined_steps(k, with_gather=True):
+        barrier()
+        h.set_option("timers", 0)
+        t0 = time.perf_counter()
+        n = 0
+        for j in range(k):
+            b = j % 2
+            closest = closest2[b]
+            h.lsi_query_async(0, 1, e0, e1, cap, pairs2[b])
+            early = h.get_option("pip_schedule") in (1, 2)
+            if early:
+                h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+            h.lsi_points_async(pairs2[b], cap, xsects)
+            if world > 1:
+                ex.begin(b)
+            else:
+                h.lsi_count_async(b)
+            if not early:
+                h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+            if pg is not None and with_gather:
+                pg.begin(closest)   # (waits, on the host, for the gather of step j - 1: its buffer is step j + 1's)
+            if j > 0:
+                if world > 1:
+                    state["pairs_all"], state["cnt_all"] = ex.finish(1 - b)
+                    n = state["cnt_all"][rank]
+                else:
+                    n = h.lsi_count_wait(1 - b, cap)
+        b = (k - 1) % 2
+        if world > 1:
+            state["pairs_all"], state["cnt_all"] = ex.finish(b)
+            n = state["cnt_all"][rank]
+        else:
+            n = h.lsi_count_wait(b, cap)
+        h.sync()
+        barrier()
+        el = time.perf_counter() - t0
+        h.set_option("timers", 1)
+        state["timers_on"] = True
+        state["n"] = n
+        state["closest"] = closest2[b]
+        state["last_pairs"] = pairs2[b]
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    def timed_pipelined(k, with_gather=True):
+        gc.disable()
+        try:
+            return pipelined_steps(k, with_gather)
+        finally:
+            gc.enable()
 
     def timed(k, with_gather=True):
         # (the interpreter's cyclic collector stays out of the timed steps: a full collection that happens to fall into
@@ -275,6 +341,14 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     settled = args.serial_kernels or never_paired or h.get_option("pip_schedule") >= 0
     elapsed = timed(steps)
     ms_per_step = elapsed * 1e3 / steps
+    ms_synced = ms_pipelined = None
+    if settled and steps >= 2:
+        el_p = timed_pipelined(steps)
+        ms_pipelined = el_p * 1e3 / steps
+        if world > 1:
+            # N > 1: the steps of the job are the pipelined ones (no host sync inside the timed region but the closing one);
+            # the synchronised form stays in the line beside it
+            ms_synced, ms_per_step, elapsed = ms_per_step, ms_pipelined, el_p
     # (the line's value is the K steps over their total time, as the contract says; the median and the slowest step say
     #  whether one stall -- another tenant of the host, a driver hiccup: seen as one 11-43 ms step among 2.8 ms ones --
     #  is in that total)
@@ -284,7 +358,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     lsi_k = float(np.mean(lsi_ms)); pip_k = float(np.mean(pip_ms)); walk_k = float(np.mean(walk_ms)) if (walk_ms and state["two_pass"]) else None
     ms_pairs_only = None
     if gather_pip:
-        ms_pairs_only = timed(steps, with_gather=False) * 1e3 / steps
+        ms_pairs_only = (timed_pipelined if ms_synced is not None else timed)(steps, with_gather=False) * 1e3 / steps
     if world > 1:
         tot = torch.tensor([state["n"]], dtype=torch.int64, device=dev)
         if dist.get_backend() == "gloo":
@@ -305,7 +379,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     # an N-rank run with the single-GPU run of the same workload without shipping the results
     def digest():
         n = state["n"]
-        pr = pairs[:n].to(torch.int64) & 0xFFFFFFFF
+        pr = state.get("last_pairs", pairs)[:n].to(torch.int64) & 0xFFFFFFFF
         xs = xsects[:n]
         pc = closest[:p1 - p0].to(torch.int64) & 0xFFFFFFFF
         hit = pc != 0xFFFFFFFF
@@ -366,7 +440,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
 
     checks = None
     if args.check and rank == 0 and world == 1 and headline:
-        checks = run_checks(h, torch, dev, n_x, cap, pairs, closest, faces, query, e0, e1)
+        checks = run_checks(h, torch, dev, n_x, cap, state.get("last_pairs", pairs), closest, faces, query, e0, e1)
 
     out = None
     if rank == 0:
@@ -477,6 +551,14 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             "roofline_step": {"bound": "hbm", "achieved": round(b_step / (ms_per_step * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(b_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_step},
         }
+        if ms_pipelined is not None:
+            out["ms_per_step_pipelined"] = round(ms_pipelined, 4)  # step j + 1 launched before step j's count / heads are read
+        if ms_synced is not None:
+            out["ms_per_step_synced"] = round(ms_synced, 4)        # every step ending in the host's read of the gathered heads
+        out["pipelined"] = ms_synced is not None
+        if world > 1:
+            out["multi_gpu_note"] = ("no hardware curve exists for N > 1 in this repository's records: this line is whatever node ran it; "
+                                     "single-GPU emulations of a shard (--emulate-shard) are diagnostics, not scaling results")
         out["ms_per_step_median"] = round(step_median_ms, 4)
         out["ms_slowest_step"] = round(step_max_ms, 4)
         if ms_pairs_only is not None:

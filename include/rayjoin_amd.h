@@ -126,6 +126,12 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found);
  * A multi-GPU caller puts it at the head of its exchange buffer and ships count + pairs in one
  * collective with no host round trip between the LSI kernel and the exchange. */
 int rj_lsi_count_to(rj_handle h, uint64_t* n_found_dev);
+/* The count of the last rj_lsi_query_async read back behind an event instead of a stream sync (two slots): a caller
+ * that pipelines steps launches step k + 1 -- into other buffers -- before it looks at step k's count, so the GPU
+ * never idles while the host wakes up.  rj_lsi_count_wait: *n_found, RJ_E_OVERFLOW / RJ_E_INTERNAL as
+ * rj_lsi_query_finish; it waits for that query (and whatever was enqueued before rj_lsi_count_async) only. */
+int rj_lsi_count_async(rj_handle h, int slot);
+int rj_lsi_count_wait(rj_handle h, int slot, uint64_t capacity, uint64_t* n_found);
 
 /* replaces: the intersection-point half of dev::intersect_test + the narrowing store into
  * Intersection<int64_t> (src/algo/lsi.h:107-143, src/app/lsi_lbvh.h:71-78).
@@ -164,7 +170,6 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
  * learned, e.g. before a buffer is reused for unrelated points. */
 int rj_invalidate(rj_handle h);
 
-/* ---- multi-GPU: RCCL over xGMI ---------------------------------------------------------- */
 /* ---- -mode=grid on the device (the reference's third index, for the grid / lbvh / rt comparison)
  * replaces: UniformGrid::AddMapsToGrid / AddMapToGrid (src/grid/uniform_grid.h:132-349): one CSR per
  * map over grid_size x grid_size cells of the scaled domain (calculate_cell, src/grid/cell.h:16-22);
@@ -181,20 +186,55 @@ int rj_lsi_query_grid(rj_handle h, uint64_t capacity, uint32_t* pairs_dev, uint6
 int rj_pip_query_grid(rj_handle h, int base_map_id, int query_map_id, const int64_t* pts_dev,
                       uint64_t pt_begin, uint64_t n, uint32_t* closest_eid_dev, int32_t* face_id_dev);
 
+/* ---- multi-GPU: RCCL over xGMI ---------------------------------------------------------- */
 /* New design (the reference is single-GPU: no NCCL/MPI anywhere).  One process and
  * one handle per GPU; the query map is sharded by chain range (rj_lsi_query's eid range / the point
  * range of rj_pip_query), the base map + LBVH are replicated, and the result queues are exchanged
- * with an all-gather-v: counts first (ncclAllGather), then every rank's exact slice straight into
- * its offset of the output (grouped ncclSend/ncclRecv -- no padding).
+ * with an all-gather-v.  Every exchange below is made of ncclAllGather alone and takes no
+ * rank-dependent branch between two collectives: what a rank does next is a function of the
+ * gathered words, which are the same everywhere.
  * rj_comm_unique_id: call on ONE rank, hand the 128 bytes to the others out of band (file, env,
- * MPI, torch.distributed store ...).  rj_comm_init is collective. */
+ * MPI, torch.distributed store ...).  rj_comm_init is collective (it makes two communicators: pair
+ * queues and point queues travel on streams of their own and never wait for each other). */
 #define RJ_COMM_ID_BYTES 128
 int rj_comm_unique_id(uint8_t id[RJ_COMM_ID_BYTES]);
 int rj_comm_init(rj_handle h, int nranks, int rank, const uint8_t id[RJ_COMM_ID_BYTES]);
 int rj_comm_destroy(rj_handle h);
-/* pairs_dev: this rank's n_local (eid0, eid1) pairs; out_dev[2 * out_capacity]: all ranks' pairs in
- * rank order; counts_out[nranks] (host, nullable); *n_total = sum.  RJ_E_OVERFLOW (with *n_total
- * set) when the total exceeds out_capacity. */
+
+/* The exchange of a STEP, off the critical path (bench.py, query_exec -nranks).  rj_exchange_init registers one or two
+ * CALLER-OWNED exchange buffers of RJ_EXCHANGE_HEAD_WORDS + 2 * capacity 32-bit words each (buf1_dev nullable; every rank
+ * must pass the same capacity and slot): the handle keeps a head in front -- count (u64), capacity (u64) -- and the
+ * caller hands bufK_dev + RJ_EXCHANGE_HEAD_WORDS to rj_lsi_query_async as pairs_dev.  Per step:
+ *   rj_lsi_query_async(h, ..., capacity, bufK_dev + RJ_EXCHANGE_HEAD_WORDS);
+ *   rj_exchange_pairs_begin(h, K);        the device-side count goes into the buffer's head and ONE ncclAllGather of
+ *                                         head + `slot` pairs per rank starts on the communication stream behind an
+ *                                         event: no host round trip between the LSI kernel and the collective
+ *   ... rj_lsi_points_async, rj_pip_query_async, the next step into the other buffer ...
+ *   rj_exchange_pairs_finish(h, K, counts, slices, &total);   the step's one host sync on the LSI side: counts_out
+ *                                         [nranks] (host), slices_dev[nranks] = device pointers to every rank's pairs
+ *                                         (handle-owned, valid until the buffer's next begin), *n_total = sum.
+ * `slot` (pairs shipped per rank) follows twice the largest count seen; a step in which some rank found more is gathered
+ * again with a larger slot -- by every rank, which all see the same counts.  RJ_E_OVERFLOW, on EVERY rank, when some
+ * rank's queue overflowed its capacity. */
+#define RJ_EXCHANGE_HEAD_WORDS 4
+int rj_exchange_init(rj_handle h, uint64_t capacity, uint64_t slot, uint32_t* buf0_dev, uint32_t* buf1_dev);
+int rj_exchange_pairs_begin(rj_handle h, int buf);
+int rj_exchange_pairs_finish(rj_handle h, int buf, uint64_t* counts_out, const uint32_t** slices_dev, uint64_t* n_total);
+/* The PIP result queues of contiguous point shards: every rank ships n_per_rank words (its shard, padded: the same
+ * n on every rank), recv_dev[nranks * n_per_rank].  Starts behind everything enqueued so far on the handle's streams, on
+ * the second communicator's stream; rj_exchange_u32_finish waits for it. */
+int rj_exchange_u32_begin(rj_handle h, const uint32_t* src_dev, uint64_t n_per_rank, uint32_t* recv_dev);
+int rj_exchange_u32_finish(rj_handle h);
+/* what every rank concludes from the gathered (count, capacity) words -- a pure host function (no GPU, no
+ * communicator), so that the branch after a collective can be tested without one: RJ_E_OVERFLOW when some rank's count
+ * exceeds its capacity (*first_bad = the lowest such rank, else -1), *max_count = the largest count. */
+int rj_exchange_verdict(const uint64_t* counts, const uint64_t* capacities, int nranks, uint64_t* max_count, int* first_bad);
+
+/* Synchronous all-gather-v with exact, contiguous output (hosts that want one flat queue).
+ * pairs_dev: this rank's n_local (eid0, eid1) pairs; out_dev[2 * out_capacity]: all ranks' pairs in
+ * rank order; counts_out[nranks] (host, nullable); *n_total = sum.  Two collectives: (count, capacity) of every rank,
+ * then every slice padded to the largest.  RJ_E_OVERFLOW (with *n_total set) on EVERY rank when the total exceeds the
+ * SMALLEST out_capacity any rank passed -- no rank enters the second collective alone. */
 int rj_allgather_pairs(rj_handle h, const uint32_t* pairs_dev, uint64_t n_local, uint32_t* out_dev,
                        uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total);
 /* The layout of an all-gather-v, as a pure host function (no GPU, no communicator; what rj_allgather_* compute

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RAYJOIN_AMD_LIB") or os.path.join(HERE, "librayjoin_amd.so")  # override: A/B builds
 
 RJ_OK, RJ_E_INVALID, RJ_E_HIP, RJ_E_OVERFLOW, RJ_E_NOMEM, RJ_E_INTERNAL = 0, 1, 2, 3, 4, 5
+RJ_EXCHANGE_HEAD_WORDS = 4
 RJ_T_BUILD, RJ_T_LSI_KERNEL, RJ_T_PIP_KERNEL, RJ_T_LSI_POINTS, RJ_T_SORT, RJ_T_ORDER = 0, 1, 2, 3, 4, 5
 RJ_T_BUILD_KEYS, RJ_T_BUILD_SORT, RJ_T_BUILD_LEAVES, RJ_T_BUILD_LEVELS, RJ_T_PIP_WALK, RJ_T_BUILD_RUNS = 6, 7, 8, 9, 10, 11
 MISS_EID = 0xFFFFFFFF
@@ -41,6 +42,8 @@ SYMBOLS = {
     "rj_lsi_query_async": (_int, [_vp, _int, _int, _u64, _u64, _u64, _vp]),
     "rj_lsi_query_finish": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "rj_lsi_count_to": (_int, [_vp, _vp]),
+    "rj_lsi_count_async": (_int, [_vp, _int]),
+    "rj_lsi_count_wait": (_int, [_vp, _int, _u64, C.POINTER(_u64)]),
     "rj_lsi_points": (_int, [_vp, _vp, _u64, _vp]),
     "rj_lsi_points_async": (_int, [_vp, _vp, _u64, _vp]),
     "rj_sort_pairs": (_int, [_vp, _vp, _u64]),
@@ -50,6 +53,12 @@ SYMBOLS = {
     "rj_allgather_pairs": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
     "rj_allgather_u32": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, C.POINTER(_u64)]),
     "rj_allgatherv_plan": (_int, [_vp, _int, _u64, _vp, C.POINTER(_u64)]),
+    "rj_exchange_init": (_int, [_vp, _u64, _u64, _vp, _vp]),
+    "rj_exchange_pairs_begin": (_int, [_vp, _int]),
+    "rj_exchange_pairs_finish": (_int, [_vp, _int, _vp, _vp, C.POINTER(_u64)]),
+    "rj_exchange_u32_begin": (_int, [_vp, _vp, _u64, _vp]),
+    "rj_exchange_u32_finish": (_int, [_vp]),
+    "rj_exchange_verdict": (_int, [_vp, _vp, _int, C.POINTER(_u64), C.POINTER(_int)]),
     "rj_last_ms_all": (_int, [_vp, _vp, _int]),
     "rj_graph_begin": (_int, [_vp, _int]),
     "rj_graph_end": (_int, [_vp]),
@@ -81,6 +90,15 @@ def kernel_source_hash():
         with open(os.path.join(HERE, "csrc", name), "rb") as f:
             hsh.update(f.read())
     return hsh.hexdigest()[:16]
+
+
+def exchange_verdict(counts, capacities):
+    """rj_exchange_verdict: (status, max_count, first_bad) every rank concludes from the gathered (count, capacity) words"""
+    counts = np.ascontiguousarray(counts, dtype=np.uint64)
+    caps = np.ascontiguousarray(capacities, dtype=np.uint64)
+    mx, bad = _u64(0), _int(-1)
+    rc = load().rj_exchange_verdict(counts.ctypes.data, caps.ctypes.data, int(counts.shape[0]), C.byref(mx), C.byref(bad))
+    return rc, mx.value, bad.value
 
 
 def allgatherv_plan(counts, capacity):
@@ -306,6 +324,17 @@ class Handle:
         self._check(self.L.rj_pip_query_grid(self.h, base_map_id, query_map_id, _ptr(pts_dev), pt_begin, n,
                                              _ptr(closest_dev), _ptr(face_dev)))
 
+    def lsi_count_async(self, slot):
+        self._check(self.L.rj_lsi_count_async(self.h, slot))
+
+    def lsi_count_wait(self, slot, capacity):
+        n = _u64()
+        rc = self.L.rj_lsi_count_wait(self.h, slot, capacity, C.byref(n))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
+        self._check(rc)
+        return n.value
+
     def lsi_count_to(self, n_found_dev):
         """device-side Queue::size: copy the last async LSI's count (u64) to device memory, on the stream"""
         self._check(self.L.rj_lsi_count_to(self.h, _ptr(n_found_dev)))
@@ -332,6 +361,29 @@ class Handle:
 
     def comm_destroy(self):
         self._check(self.L.rj_comm_destroy(self.h))
+
+    def exchange_init(self, capacity, slot, buf0_dev, buf1_dev=None):
+        self._check(self.L.rj_exchange_init(self.h, capacity, slot, _ptr(buf0_dev), _ptr(buf1_dev)))
+
+    def exchange_pairs_begin(self, buf):
+        self._check(self.L.rj_exchange_pairs_begin(self.h, buf))
+
+    def exchange_pairs_finish(self, buf, nranks):
+        """-> (counts list, device pointers of every rank's pairs, total); raises QueueOverflow on every rank alike"""
+        counts = (_u64 * nranks)()
+        slices = (_vp * nranks)()
+        total = _u64()
+        rc = self.L.rj_exchange_pairs_finish(self.h, buf, counts, slices, C.byref(total))
+        if rc == RJ_E_OVERFLOW:
+            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), total.value)
+        self._check(rc)
+        return list(counts), [s or 0 for s in slices], total.value
+
+    def exchange_u32_begin(self, src_dev, n_per_rank, recv_dev):
+        self._check(self.L.rj_exchange_u32_begin(self.h, _ptr(src_dev), n_per_rank, _ptr(recv_dev)))
+
+    def exchange_u32_finish(self):
+        self._check(self.L.rj_exchange_u32_finish(self.h))
 
     def _allgather(self, fn, src_dev, n_local, out_dev, out_capacity):
         counts = (_u64 * getattr(self, "nranks", 1))()

@@ -67,6 +67,7 @@ constexpr int kNumTimers = 12;
 // average (w + h) of a 64-query group's quantised box above which the query set is re-ordered
 // along the Morton curve before the kernels run (the domain is 2^31 wide per axis)
 constexpr unsigned long long kIncoherentExtent = 1ull << 28;
+constexpr uint64_t kExchHead = RJ_EXCHANGE_HEAD_WORDS;  // 32-bit words in front of the pairs of an exchange buffer: count (u64), capacity (u64)
 constexpr int kCoTrials = 4;  // measured LSI + PIP pairs before "pip_concurrent" 2 settles on a schedule
 
 }  // namespace
@@ -224,6 +225,32 @@ struct rj_handle_s {
   char* arena = nullptr;
   size_t arena_bytes = 0;
   ncclComm_t comm = nullptr;
+  // The exchange of a step (rj_exchange_*): ONE collective per queue, symmetric on every rank by construction (nothing
+  // but ncclAllGather, no rank-dependent branch between collectives).  The pair queues travel as [count u64 | capacity
+  // u64 | pairs ...] -- the count is stamped on the device, so no host round trip sits between the LSI kernel and the
+  // collective -- on a communication stream of their own behind an event; the PIP result queues on a second
+  // communicator and stream (two collectives of one communicator must not be in flight together), so that a step's
+  // point gather never queues in front of the next step's pair exchange.  Two buffers each: step k + 1 can be launched
+  // before step k's heads have been read.
+  ncclComm_t comm2 = nullptr;
+  hipStream_t comm_stream = nullptr, comm_stream2 = nullptr;
+  hipEvent_t ev_comm = nullptr, ev_comm2 = nullptr, ev_comm2_aux = nullptr;
+  struct Exch {
+    uint32_t* send = nullptr;   // caller-owned, [RJ_EXCHANGE_HEAD_WORDS + 2 capacity] words: the LSI query writes its pairs behind the head
+    uint32_t* recv = nullptr;   // [nranks][kExchHead + 2 slot]
+    uint64_t recv_words = 0, slot = 0;
+    bool pending = false;
+  } ex[2];
+  uint64_t ex_capacity = 0, ex_slot = 0;
+  int ex_last_begin = -1;   // the buffer of the latest LSI query handed to the exchange
+  // rj_lsi_count_async / rj_lsi_count_wait: the count of an asynchronous LSI query read back behind an event, so that the
+  // host can launch the next step before it looks at this one's count (two slots)
+  hipEvent_t ev_count[2] = {nullptr, nullptr};
+  bool count_pending[2] = {false, false};
+  unsigned long long* h_heads = nullptr;  // pinned [3][nranks][2]: the gathered (count, capacity) words -- of exchange buffer 0 / 1, of rj_allgather_*
+  uint32_t* ag_send = nullptr;  // grow-only staging of the synchronous rj_allgather_* forms (padded slices)
+  uint32_t* ag_recv = nullptr;
+  uint64_t ag_send_words = 0, ag_recv_words = 0;
   int nranks = 1, rank = 0;
   unsigned long long* d_counts = nullptr;  // [nranks] gathered counts
   std::string err;
@@ -441,6 +468,8 @@ int rj_create(int device_id, rj_handle* out) {
   }
   for (int t = 0; ok && t < kNumTimers; t++)
     ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_count[0], hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->ev_count[1], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -467,6 +496,7 @@ int rj_destroy(rj_handle h) {
   (void) hipHostFree(h->h_rest); (void) hipFree(h->rest[0]); (void) hipFree(h->rest[1]); (void) hipFree(h->todo[0]); (void) hipFree(h->todo[1]); (void) hipFree(h->todo_mask[0]); (void) hipFree(h->todo_mask[1]);
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
+  for (int k = 0; k < 2; k++) if (h->ev_count[k]) (void) hipEventDestroy(h->ev_count[k]);
   if (h->ev_order) (void) hipEventDestroy(h->ev_order);
   if (h->ev_fork) (void) hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void) hipEventDestroy(h->ev_join);
@@ -477,8 +507,7 @@ int rj_destroy(rj_handle h) {
     if (h->graph_aux[g]) (void) hipGraphDestroy(h->graph_aux[g]);
   }
   (void) hipFree(h->arena);
-  if (h->comm) (void) ncclCommDestroy(h->comm);
-  (void) hipFree(h->d_counts);
+  if (h->comm) (void) rj_comm_destroy(h);
   (void) hipStreamDestroy(h->own_stream);
   (void) hipStreamDestroy(h->aux_stream);
   delete h;
@@ -1147,6 +1176,32 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   return RJ_OK;
 }
 
+int rj_lsi_count_async(rj_handle h, int slot) {
+  RJ_CHECK_H(h);
+  if (slot < 0 || slot > 1) return fail(h, RJ_E_INVALID, "rj_lsi_count_async: slot is 0 or 1");
+  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_lsi_count_async: a step is being captured");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 28 + slot, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipEventRecord(h->ev_count[slot], h->stream));
+  h->count_pending[slot] = true;
+  return RJ_OK;
+}
+
+int rj_lsi_count_wait(rj_handle h, int slot, uint64_t capacity, uint64_t* n_found) {
+  RJ_CHECK_H(h);
+  if (slot < 0 || slot > 1 || !h->count_pending[slot]) return fail(h, RJ_E_INVALID, "rj_lsi_count_wait: no count in flight in slot %d", slot);
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipEventSynchronize(h->ev_count[slot]));
+  h->count_pending[slot] = false;
+  const uint64_t n = h->h_pinned[28 + slot];
+  h->h_rest[2] = n;
+  if (n_found) *n_found = n;
+  if (int r = check_fault(h)) return r;
+  if (n > capacity)
+    return fail(h, RJ_E_OVERFLOW, "intersection queue overflow: %llu found, capacity %llu", (unsigned long long) n, (unsigned long long) capacity);
+  return RJ_OK;
+}
+
 int rj_lsi_count_to(rj_handle h, uint64_t* n_found_dev) {
   RJ_CHECK_H(h);
   if (!n_found_dev) return fail(h, RJ_E_INVALID, "rj_lsi_count_to: null destination");
@@ -1566,6 +1621,14 @@ int rj_comm_unique_id(uint8_t id[RJ_COMM_ID_BYTES]) {
   return RJ_OK;
 }
 
+static void free_exchange(rj_handle h) {
+  for (int k = 0; k < 2; k++) {
+    (void) hipFree(h->ex[k].recv);  // (the send buffers are the caller's)
+    h->ex[k] = rj_handle_s::Exch();
+  }
+  h->ex_capacity = h->ex_slot = 0;
+}
+
 int rj_comm_init(rj_handle h, int nranks, int rank, const uint8_t id[RJ_COMM_ID_BYTES]) {
   RJ_CHECK_H(h);
   if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, RJ_E_INVALID, "rj_comm_init: bad arguments");
@@ -1574,9 +1637,17 @@ int rj_comm_init(rj_handle h, int nranks, int rank, const uint8_t id[RJ_COMM_ID_
   ncclUniqueId u;
   memcpy(u.internal, id, RJ_COMM_ID_BYTES);
   RJ_NCCL(h, ncclCommInitRank(&h->comm, nranks, u, rank));
+  // the second communicator (point queues): same ranks, its own stream -- collective on every rank, like the first
+  RJ_NCCL(h, ncclCommSplit(h->comm, 0, rank, &h->comm2, nullptr));
   h->nranks = nranks;
   h->rank = rank;
-  if (int r = dev_alloc(h, &h->d_counts, (uint64_t) nranks)) return r;
+  if (int r = dev_alloc(h, &h->d_counts, 2 * (uint64_t) nranks)) return r;
+  RJ_HIP(h, hipHostMalloc((void**) &h->h_heads, 3 * 16 * (size_t) nranks));
+  RJ_HIP(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+  RJ_HIP(h, hipStreamCreateWithFlags(&h->comm_stream2, hipStreamNonBlocking));
+  RJ_HIP(h, hipEventCreateWithFlags(&h->ev_comm, hipEventDisableTiming));
+  RJ_HIP(h, hipEventCreateWithFlags(&h->ev_comm2, hipEventDisableTiming));
+  RJ_HIP(h, hipEventCreateWithFlags(&h->ev_comm2_aux, hipEventDisableTiming));
   return RJ_OK;
 }
 
@@ -1585,10 +1656,22 @@ int rj_comm_destroy(rj_handle h) {
   if (h->comm) {
     if (int r = set_device(h)) return r;
     RJ_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->comm_stream) RJ_HIP(h, hipStreamSynchronize(h->comm_stream));
+    if (h->comm_stream2) RJ_HIP(h, hipStreamSynchronize(h->comm_stream2));
+    if (h->comm2) RJ_NCCL(h, ncclCommDestroy(h->comm2));
     RJ_NCCL(h, ncclCommDestroy(h->comm));
-    h->comm = nullptr;
-    (void) hipFree(h->d_counts);
-    h->d_counts = nullptr;
+    h->comm = h->comm2 = nullptr;
+    free_exchange(h);
+    (void) hipFree(h->d_counts); (void) hipFree(h->ag_send); (void) hipFree(h->ag_recv);
+    (void) hipHostFree(h->h_heads);
+    h->d_counts = nullptr; h->ag_send = h->ag_recv = nullptr; h->ag_send_words = h->ag_recv_words = 0; h->h_heads = nullptr;
+    if (h->comm_stream) (void) hipStreamDestroy(h->comm_stream);
+    if (h->comm_stream2) (void) hipStreamDestroy(h->comm_stream2);
+    if (h->ev_comm) (void) hipEventDestroy(h->ev_comm);
+    if (h->ev_comm2) (void) hipEventDestroy(h->ev_comm2);
+    if (h->ev_comm2_aux) (void) hipEventDestroy(h->ev_comm2_aux);
+    h->comm_stream = h->comm_stream2 = nullptr;
+    h->ev_comm = h->ev_comm2 = h->ev_comm2_aux = nullptr;
     h->nranks = 1;
     h->rank = 0;
   }
@@ -1607,42 +1690,69 @@ int rj_allgatherv_plan(const uint64_t* counts, int nranks, uint64_t capacity, ui
   return sum > capacity ? RJ_E_OVERFLOW : RJ_OK;
 }
 
-// all-gather-v of n_local elements of `elt_words` 32-bit words each
+int rj_exchange_verdict(const uint64_t* counts, const uint64_t* capacities, int nranks, uint64_t* max_count, int* first_bad) {
+  if (!counts || !capacities || nranks < 1) return RJ_E_INVALID;
+  uint64_t mx = 0;
+  int bad = -1;
+  for (int r = 0; r < nranks; r++) {
+    if (counts[r] > mx) mx = counts[r];
+    if (bad < 0 && counts[r] > capacities[r]) bad = r;
+  }
+  if (max_count) *max_count = mx;
+  if (first_bad) *first_bad = bad;
+  return bad >= 0 ? RJ_E_OVERFLOW : RJ_OK;
+}
+
+// all-gather-v of n_local elements of `elt_words` 32-bit words each, synchronous, exact slices at their offsets.
+// Two symmetric collectives: (count, output capacity) of every rank, then every rank's slice padded to the largest
+// count.  The verdict between them is a function of the gathered words alone, so every rank takes the same branch:
+// if the total does not fit SOME rank's output, every rank returns RJ_E_OVERFLOW and no rank enters the second
+// collective (round 3's form compared the total with the rank's own capacity only: ranks called with different
+// capacities parted ways, and the others hung in ncclRecv).
 static int allgatherv_words(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uint32_t* out_dev,
                             uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total, int elt_words) {
   if (!h->comm) return fail(h, RJ_E_INVALID, "call rj_comm_init first");
   if ((n_local && !src_dev) || (out_capacity && !out_dev)) return fail(h, RJ_E_INVALID, "null buffer");
   if (int r = set_device(h)) return r;
   const int P = h->nranks;
-  // 1. counts
-  unsigned long long mine = n_local;
-  RJ_HIP(h, hipMemcpyAsync(h->d_counts + h->rank, &mine, 8, hipMemcpyHostToDevice, h->stream));
-  RJ_NCCL(h, ncclAllGather(h->d_counts + h->rank, h->d_counts, 1, ncclUint64, h->comm, h->stream));
-  std::vector<unsigned long long> cnt(P);
-  RJ_HIP(h, hipMemcpyAsync(cnt.data(), h->d_counts, 8 * (size_t) P, hipMemcpyDeviceToHost, h->stream));
+  const size_t w = (size_t) elt_words;
+  // 1. counts and capacities
+  unsigned long long mine[2] = {n_local, out_capacity};
+  RJ_HIP(h, hipMemcpyAsync(h->d_counts + 2 * h->rank, mine, 16, hipMemcpyHostToDevice, h->stream));
+  RJ_NCCL(h, ncclAllGather(h->d_counts + 2 * h->rank, h->d_counts, 2, ncclUint64, h->comm, h->stream));
+  unsigned long long* heads = h->h_heads + 4 * (size_t) P;
+  RJ_HIP(h, hipMemcpyAsync(heads, h->d_counts, 16 * (size_t) P, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
-  uint64_t total = 0;
-  std::vector<uint64_t> off(P), cnt64(cnt.begin(), cnt.end());
-  const int plan = rj_allgatherv_plan(cnt64.data(), P, out_capacity, off.data(), &total);
-  for (int r = 0; r < P && counts_out; r++) counts_out[r] = cnt[r];
+  std::vector<uint64_t> cnt(P), off(P);
+  uint64_t total = 0, min_cap = UINT64_MAX, mx = 0;
+  for (int r = 0; r < P; r++) {
+    cnt[r] = heads[2 * r];
+    if (heads[2 * r + 1] < min_cap) min_cap = heads[2 * r + 1];
+    if (cnt[r] > mx) mx = cnt[r];
+    if (counts_out) counts_out[r] = cnt[r];
+  }
+  const int plan = rj_allgatherv_plan(cnt.data(), P, min_cap, off.data(), &total);
   if (n_total) *n_total = total;
   if (plan == RJ_E_OVERFLOW)
-    return fail(h, RJ_E_OVERFLOW, "all-gather-v: %llu elements in total, capacity %llu", (unsigned long long) total,
-                (unsigned long long) out_capacity);
+    return fail(h, RJ_E_OVERFLOW, "all-gather-v: %llu elements in total, the smallest output capacity of a rank is %llu (this rank: %llu)",
+                (unsigned long long) total, (unsigned long long) min_cap, (unsigned long long) out_capacity);
   if (plan != RJ_OK) return fail(h, plan, "all-gather-v: bad counts");
-  // 2. exact slices: my slice goes to every peer, every peer's slice lands at its offset here
-  const size_t w = (size_t) elt_words;
-  if (n_local)
-    RJ_HIP(h, hipMemcpyAsync(out_dev + off[h->rank] * w, src_dev, n_local * w * 4, hipMemcpyDeviceToDevice, h->stream));
-  if (P > 1) {
-    RJ_NCCL(h, ncclGroupStart());
-    for (int r = 0; r < P; r++) {
-      if (r == h->rank) continue;
-      if (n_local) RJ_NCCL(h, ncclSend(src_dev, n_local * w, ncclUint32, r, h->comm, h->stream));
-      if (cnt[r]) RJ_NCCL(h, ncclRecv(out_dev + off[r] * w, cnt[r] * w, ncclUint32, r, h->comm, h->stream));
-    }
-    RJ_NCCL(h, ncclGroupEnd());
+  if (mx == 0) return RJ_OK;
+  // 2. every rank's slice, padded to the largest: one ncclAllGather, then the slices go to their offsets
+  if (h->ag_send_words < mx * w) {
+    (void) hipFree(h->ag_send); h->ag_send = nullptr; h->ag_send_words = 0;
+    if (int r = dev_alloc(h, &h->ag_send, mx * w)) return r;
+    h->ag_send_words = mx * w;
   }
+  if (h->ag_recv_words < (uint64_t) P * mx * w) {
+    (void) hipFree(h->ag_recv); h->ag_recv = nullptr; h->ag_recv_words = 0;
+    if (int r = dev_alloc(h, &h->ag_recv, (uint64_t) P * mx * w)) return r;
+    h->ag_recv_words = (uint64_t) P * mx * w;
+  }
+  if (n_local) RJ_HIP(h, hipMemcpyAsync(h->ag_send, src_dev, n_local * w * 4, hipMemcpyDeviceToDevice, h->stream));
+  RJ_NCCL(h, ncclAllGather(h->ag_send, h->ag_recv, mx * w, ncclUint32, h->comm, h->stream));
+  for (int r = 0; r < P; r++)
+    if (cnt[r]) RJ_HIP(h, hipMemcpyAsync(out_dev + off[r] * w, h->ag_recv + (size_t) r * mx * w, cnt[r] * w * 4, hipMemcpyDeviceToDevice, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   return RJ_OK;
 }
@@ -1657,6 +1767,114 @@ int rj_allgather_u32(rj_handle h, const uint32_t* src_dev, uint64_t n_local, uin
                      uint64_t out_capacity, uint64_t* counts_out, uint64_t* n_total) {
   RJ_CHECK_H(h);
   return allgatherv_words(h, src_dev, n_local, out_dev, out_capacity, counts_out, n_total, 1);
+}
+
+// ---- the overlapped exchange of a step --------------------------------------------------------
+int rj_exchange_init(rj_handle h, uint64_t capacity, uint64_t slot, uint32_t* buf0_dev, uint32_t* buf1_dev) {
+  RJ_CHECK_H(h);
+  if (!h->comm) return fail(h, RJ_E_INVALID, "rj_exchange_init: call rj_comm_init first");
+  if (capacity == 0 || capacity >= (1ull << 31) || !buf0_dev) return fail(h, RJ_E_INVALID, "rj_exchange_init: capacity out of range or null buffer");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->comm_stream));
+  free_exchange(h);
+  h->ex_capacity = capacity;
+  h->ex_slot = slot < 1 ? 1 : (slot > capacity ? capacity : slot);
+  const unsigned long long head[2] = {0, capacity};
+  h->ex[0].send = buf0_dev;
+  h->ex[1].send = buf1_dev;
+  for (int k = 0; k < 2; k++)
+    if (h->ex[k].send) RJ_HIP(h, hipMemcpy(h->ex[k].send, head, 16, hipMemcpyHostToDevice));
+  return RJ_OK;
+}
+
+static int exchange_gather(rj_handle h, int buf, uint64_t slot, hipStream_t st) {
+  rj_handle_s::Exch& x = h->ex[buf];
+  const uint64_t per_rank = kExchHead + 2 * slot, need = (uint64_t) h->nranks * per_rank;
+  if (x.recv_words < need) {
+    RJ_HIP(h, hipStreamSynchronize(h->comm_stream));  // (the old buffer may be the target of a collective in flight)
+    (void) hipFree(x.recv); x.recv = nullptr; x.recv_words = 0;
+    if (int r = dev_alloc(h, &x.recv, need)) return r;
+    x.recv_words = need;
+  }
+  x.slot = slot;
+  RJ_NCCL(h, ncclAllGather(x.send, x.recv, per_rank, ncclUint32, h->comm, st));
+  // the heads, packed, into pinned memory behind the collective
+  RJ_HIP(h, hipMemcpy2DAsync(h->h_heads + 2 * (size_t) h->nranks * buf, 16, x.recv, per_rank * 4, 16, (size_t) h->nranks, hipMemcpyDeviceToHost, st));
+  return RJ_OK;
+}
+
+int rj_exchange_pairs_begin(rj_handle h, int buf) {
+  RJ_CHECK_H(h);
+  if (buf < 0 || buf > 1 || !h->ex[buf].send) return fail(h, RJ_E_INVALID, "rj_exchange_pairs_begin: rj_exchange_init first (with this buffer); buf is 0 or 1");
+  if (h->ex[buf].pending) return fail(h, RJ_E_INVALID, "rj_exchange_pairs_begin: buffer %d has an exchange in flight (rj_exchange_pairs_finish first)", buf);
+  if (int r = set_device(h)) return r;
+  // the device-side count of the LSI query that was just launched into this buffer goes into its head, on the
+  // handle's stream; the collective waits for that point of the stream and no further
+  RJ_HIP(h, hipMemcpyAsync(h->ex[buf].send, h->d_counter + h->count_word, 8, hipMemcpyDeviceToDevice, h->stream));
+  RJ_HIP(h, hipEventRecord(h->ev_comm, h->stream));
+  RJ_HIP(h, hipStreamWaitEvent(h->comm_stream, h->ev_comm, 0));
+  if (int r = exchange_gather(h, buf, h->ex_slot, h->comm_stream)) return r;
+  h->ex[buf].pending = true;
+  h->ex_last_begin = buf;
+  return RJ_OK;
+}
+
+int rj_exchange_pairs_finish(rj_handle h, int buf, uint64_t* counts_out, const uint32_t** slices_dev, uint64_t* n_total) {
+  RJ_CHECK_H(h);
+  if (buf < 0 || buf > 1 || !h->ex[buf].pending) return fail(h, RJ_E_INVALID, "rj_exchange_pairs_finish: no exchange in flight on buffer %d", buf);
+  if (int r = set_device(h)) return r;
+  rj_handle_s::Exch& x = h->ex[buf];
+  const int P = h->nranks;
+  RJ_HIP(h, hipStreamSynchronize(h->comm_stream));  // the step's one host sync (on the LSI side)
+  x.pending = false;
+  if (buf == h->ex_last_begin) h->lsi_shared = h->lsi_inflight = false;  // (not when a later step's LSI query is already in flight)
+  std::vector<uint64_t> cnt(P), cap(P);
+  const unsigned long long* heads = h->h_heads + 2 * (size_t) P * buf;
+  for (int r = 0; r < P; r++) { cnt[r] = heads[2 * r]; cap[r] = heads[2 * r + 1]; }
+  uint64_t mx = 0, total = 0;
+  int bad = -1;
+  const int verdict = rj_exchange_verdict(cnt.data(), cap.data(), P, &mx, &bad);
+  for (int r = 0; r < P; r++) { total += cnt[r]; if (counts_out) counts_out[r] = cnt[r]; }
+  if (n_total) *n_total = total;
+  h->h_rest[2] = cnt[h->rank];  // (how many records a query like this one asks for: lsi_points_on_stream)
+  if (int r = check_fault(h)) return r;
+  if (verdict == RJ_E_OVERFLOW)  // the same words on every rank: every rank returns here
+    return fail(h, RJ_E_OVERFLOW, "intersection queue overflow on rank %d: %llu found, capacity %llu", bad,
+                (unsigned long long) cnt[bad], (unsigned long long) cap[bad]);
+  if (mx > x.slot) {
+    // (rare) some rank found more than a slot ships: every rank sees that, every rank gathers again with the same
+    // larger slot -- the send buffer still holds this step's queue
+    h->ex_slot = 2 * mx > h->ex_capacity ? h->ex_capacity : 2 * mx;
+    if (int r = exchange_gather(h, buf, h->ex_slot, h->comm_stream)) return r;
+    RJ_HIP(h, hipStreamSynchronize(h->comm_stream));
+  } else if (4 * mx < h->ex_slot && h->ex_slot > 4096) {
+    h->ex_slot = 2 * mx > 4096 ? 2 * mx : 4096;  // shrink for the next step
+  }
+  for (int r = 0; r < P && slices_dev; r++) slices_dev[r] = x.recv + (size_t) r * (kExchHead + 2 * x.slot) + kExchHead;
+  return RJ_OK;
+}
+
+int rj_exchange_u32_begin(rj_handle h, const uint32_t* src_dev, uint64_t n_per_rank, uint32_t* recv_dev) {
+  RJ_CHECK_H(h);
+  if (!h->comm2) return fail(h, RJ_E_INVALID, "rj_exchange_u32_begin: call rj_comm_init first");
+  if (n_per_rank && (!src_dev || !recv_dev)) return fail(h, RJ_E_INVALID, "rj_exchange_u32_begin: null buffer");
+  if (int r = set_device(h)) return r;
+  // behind everything enqueued so far on BOTH of the handle's streams (the PIP kernels run on either)
+  RJ_HIP(h, hipEventRecord(h->ev_comm2, h->stream));
+  RJ_HIP(h, hipStreamWaitEvent(h->comm_stream2, h->ev_comm2, 0));
+  RJ_HIP(h, hipEventRecord(h->ev_comm2_aux, h->aux_stream));
+  RJ_HIP(h, hipStreamWaitEvent(h->comm_stream2, h->ev_comm2_aux, 0));
+  if (n_per_rank) RJ_NCCL(h, ncclAllGather(src_dev, recv_dev, n_per_rank, ncclUint32, h->comm2, h->comm_stream2));
+  return RJ_OK;
+}
+
+int rj_exchange_u32_finish(rj_handle h) {
+  RJ_CHECK_H(h);
+  if (!h->comm2) return fail(h, RJ_E_INVALID, "rj_exchange_u32_finish: call rj_comm_init first");
+  if (int r = set_device(h)) return r;
+  RJ_HIP(h, hipStreamSynchronize(h->comm_stream2));
+  return RJ_OK;
 }
 
 int rj_overlay_edge_xsects(rj_handle h, int im, const uint32_t* pairs_dev, uint64_t n, rj_xsect* xsects_dev) {

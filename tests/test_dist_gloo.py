@@ -49,17 +49,34 @@ def _worker(rank, world, port, out_dir):
     # the one-collective exchange bench.py uses on RCCL (count rides at the head of the buffer);
     # slot 16 is far too small on purpose: the first finish() must grow it and re-gather
     class _FakeHandle:  # stands in for rj_lsi_count_to: the device-side count copy
+        count = len(mine)
+
         def lsi_count_to(self, send):
-            send[0] = len(mine)
+            send[0] = self.count
             send[1] = 0
-    ex = rjd.PairExchange(cap, torch.device("cpu"), slot=16)
-    for rep in range(2):
-        ex.pairs[:len(mine)] = torch.from_numpy(mine.astype(np.int32))
-        ex.begin(_FakeHandle())
-        views, cl = ex.finish()
+    fake = _FakeHandle()
+    ex = rjd.PairExchange(fake, cap, torch.device("cpu"), slot=16)
+    assert not ex.native  # (gloo: the test transport; on "nccl" the same class drives rj_exchange_* of the C ABI)
+    for rep in range(4):
+        k = rep % 2       # both exchange buffers
+        ex.pairs[k][:len(mine)] = torch.from_numpy(mine.astype(np.int32))
+        ex.begin(k)
+        views, cl = ex.finish(k)
         assert cl == [int(c) for c in counts] and ex.slot >= max(cl)
         got2 = O.sort_pairs(torch.cat(views).numpy().astype(np.uint32))
         assert np.array_equal(got2, whole), "rank %d rep %d: PairExchange result differs" % (rank, rep)
+    # one rank's queue overflowed its capacity: EVERY rank learns it from the gathered heads and raises -- nobody walks
+    # into a further collective alone (round 3's native form returned early on the overflowing rank only)
+    fake.count = cap + 5 if rank == world - 1 else len(mine)
+    ex.begin(0)
+    try:
+        ex.finish(0)
+        raise AssertionError("rank %d: overflow on rank %d went unnoticed" % (rank, world - 1))
+    except OverflowError as e:
+        assert "rank %d" % (world - 1) in str(e)
+    fake.count = len(mine)
+    ex.begin(0)
+    assert ex.finish(0)[1] == [int(c) for c in counts]  # ... and the exchange works again afterwards
     # PIP: contiguous point shards concatenate back in point order
     p0, p1 = sh["points"]
     want = O.pip_brute(m0, 1, query.pts)
@@ -69,7 +86,7 @@ def _worker(rank, world, port, out_dir):
     assert np.array_equal(allids.numpy().astype(np.uint32), want)
     # ... and the pipelined form bench.py times (begin after a step, finish a step later, double-buffered):
     # two "steps" with different contents, each gathered buffer complete when it is read
-    pg = rjd.PointGather(max_n, torch.device("cpu"))
+    pg = rjd.PointGather(None, max_n, torch.device("cpu"))
     for rep in range(3):
         buf = torch.full((max_n,), -1, dtype=torch.int32)
         buf[:p1 - p0] = ids + rep
@@ -118,3 +135,15 @@ def test_allgatherv_plan_offsets_for_ragged_and_empty_shards():
             assert rc2 == _capi.RJ_E_OVERFLOW and total2 == total and list(off2) == list(off)  # (the true total is still reported)
     assert _capi.allgatherv_plan([], 10)[2] == _capi.RJ_E_INVALID
     assert _capi.allgatherv_plan([2 ** 63, 2 ** 63], 2 ** 64 - 1)[2] == _capi.RJ_E_INVALID  # the sum does not fit 64 bits
+
+
+def test_exchange_verdict_is_the_same_on_every_rank():
+    """What a rank does after the heads have been gathered is rj_exchange_verdict of the gathered words -- the same words
+    on every rank, so the same branch: overflow anywhere is overflow everywhere, the largest count sizes the re-gather."""
+    from rayjoin_amd import _capi
+    assert _capi.exchange_verdict([3, 0, 9], [10, 10, 10]) == (_capi.RJ_OK, 9, -1)
+    assert _capi.exchange_verdict([3, 11, 9], [10, 10, 10]) == (_capi.RJ_E_OVERFLOW, 11, 1)
+    assert _capi.exchange_verdict([3, 4, 9], [10, 3, 8]) == (_capi.RJ_E_OVERFLOW, 9, 1)   # ranks with different capacities
+    assert _capi.exchange_verdict([0] * 8, [0] * 8) == (_capi.RJ_OK, 0, -1)
+    assert _capi.exchange_verdict([2 ** 40], [2 ** 40 - 1]) == (_capi.RJ_E_OVERFLOW, 2 ** 40, 0)
+    assert _capi.exchange_verdict([], [])[0] == _capi.RJ_E_INVALID

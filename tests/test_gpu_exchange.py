@@ -38,25 +38,40 @@ def test_pair_exchange_rccl_single_rank(oracle):
         want = oracle.lsi_brute(m0, m1)
         want_pip = oracle.pip_brute(m0, 1, query.pts)
         cap = 4 * len(want)
-        ex = rjd.PairExchange(cap, dev, slot=64)  # too small on purpose: first step must re-gather
+        ex = rjd.PairExchange(h, cap, dev, slot=64)  # too small on purpose: first step must re-gather
+        assert ex.native  # RCCL through the handle's communicator (rj_exchange_*), not torch's
         closest = torch.empty(query.n_points, dtype=torch.int32, device=dev)
-        for rep in range(3):
-            h.lsi_query_async(0, 1, 0, query.n_edges, cap, ex.pairs)
-            ex.begin(h)
+        pg = rjd.PointGather(h, query.n_points, dev)
+        for rep in range(4):
+            k = rep % 2
+            h.lsi_query_async(0, 1, 0, query.n_edges, cap, ex.pairs[k])
+            ex.begin(k)
             h.pip_query(0, 1, None, 0, query.n_points, closest, None, sync=False)
-            views, counts = ex.finish()
-            assert counts == [len(want)] and ex.slot >= len(want)
+            pg.begin(closest)  # behind the PIP kernels, on the second communicator's stream
+            views, counts = ex.finish(k)
+            assert counts == [len(want)]
+            assert np.array_equal(pg.finish()[0].cpu().numpy().astype(np.uint32), want_pip)
             got = views[0].clone()
             h.sort_pairs(got, counts[0])
             assert np.array_equal(got.cpu().numpy().astype(np.uint32), want)
             torch.cuda.synchronize()
             assert np.array_equal(closest.cpu().numpy().astype(np.uint32), want_pip)
         # overflow is reported, not silently truncated
-        small = rjd.PairExchange(8, dev, slot=8)
-        h.lsi_query_async(0, 1, 0, query.n_edges, 8, small.pairs)
-        small.begin(h)
+        small = rjd.PairExchange(h, 8, dev, slot=8, nbuf=1)
+        h.lsi_query_async(0, 1, 0, query.n_edges, 8, small.pairs[0])
+        small.begin(0)
         with pytest.raises(OverflowError):
-            small.finish()
+            small.finish(0)
+        # the synchronous exact form on the same communicator
+        out = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        n = h.lsi_query(0, 1, 0, query.n_edges, cap, out)
+        flat = torch.empty((cap, 2), dtype=torch.int32, device=dev)
+        total, counts = h.allgather_pairs(out, n, flat, cap)
+        assert total == n == len(want) and list(counts) == [n]
+        h.sort_pairs(flat, n)
+        assert np.array_equal(flat[:n].cpu().numpy().astype(np.uint32), want)
+        with pytest.raises(_capi.RayJoinError):
+            h.allgather_pairs(out, n, flat, n - 1)
         h.close()
     finally:
         dist.destroy_process_group()
