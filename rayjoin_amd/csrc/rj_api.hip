@@ -33,6 +33,13 @@ struct MapState {
   // built and kept: piece p = eids [piece_begin[p], + piece_len[p]), run r = pieces [run_first[r], run_first[r + 1])
   bool runs_cut = false;
   uint32_t run_cap = 0;  // edges a run may hold (what the runs were cut with)
+  uint64_t closed_chains = 0;  // rings among the chains (counted while the runs were cut)
+  // ... and how the sorted runs share leaves (k_pack_runs): run_len[nruns], leaf_first[leaves + 1] (positions in the sorted
+  // order), scratch of the packing passes; the leaf count, known after the first build
+  uint32_t *run_len = nullptr, *leaf_first = nullptr, *pack_tmp = nullptr;
+  QBox* run_box = nullptr;
+  uint64_t packed_leaves = 0;
+  uint32_t packed_solo = 0;
   uint64_t nruns = 0, npieces = 0;
   uint32_t *piece_begin = nullptr, *piece_len = nullptr, *run_first = nullptr;
 };
@@ -48,6 +55,8 @@ struct BvhState {
   int32_t* pmx1 = nullptr;
   uint2* xtab = nullptr;
   uint32_t* occ = nullptr;
+  uint32_t* sky = nullptr;  // skyline of the map (rj_device.h kSkyShift): what the PIP kernels prove a miss with
+  bool use_sky = false;     // ... filled and used (maps of isolated rings)
   QBox* lvl[kMaxLevels] = {nullptr};  // boxes of level l, then one sibling-order word per node (rj_device.h)
   uint64_t nlvl[kMaxLevels] = {0};
   uint64_t alloc[kMaxLevels] = {0};
@@ -216,7 +225,10 @@ struct rj_handle_s {
   size_t ord_temp_bytes = 0;
   int leaf_order = 1;        // "leaf_order" (default 1, or RJ_LEAF_ORDER): what the NEXT rj_build_lbvh makes a leaf of
   int debug_run_cap = 0;     // experiments: edges per polyline run (0: by the mean chain length)
-  uint32_t stitch_stats[3] = {0, 0, 0};  // the last run cutting: ranking rounds, incidences on closed loops, rounds of the second ranking
+  int debug_pack_solo = 0;   // experiments: a run longer than this never shares its leaf (0: the default, 48)
+  int debug_pack_spread = 0; // experiments: how many times larger than its runs a shared leaf may be (0: the default, 8)
+  uint32_t stitch_stats[4] = {0, 0, 0, 0};  // the last run cutting: ranking rounds, incidences on closed loops, rounds of the second ranking, closed chains
+  int skyline = -1;          // "skyline": -1 auto (maps of isolated rings), 0 never, 1 always -- what the NEXT rj_build_lbvh does
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
   int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
@@ -289,6 +301,7 @@ int dev_alloc(rj_handle h, T** p, uint64_t count) {
 void free_map(MapState& m) {
   (void) hipFree(m.pts); (void) hipFree(m.seg); (void) hipFree(m.edge_chain); (void) hipFree(m.ccode); (void) hipFree(m.left); (void) hipFree(m.right); (void) hipFree(m.edge_begin);
   (void) hipFree(m.piece_begin); (void) hipFree(m.piece_len); (void) hipFree(m.run_first);
+  (void) hipFree(m.run_len); (void) hipFree(m.leaf_first); (void) hipFree(m.pack_tmp); (void) hipFree(m.run_box);
   m = MapState();
 }
 
@@ -298,14 +311,14 @@ void free_grid(GridState& g) {
 }
 
 void free_bvh(BvhState& b) {
-  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ);
+  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
 
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
-  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.occ = b.occ;
+  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.occ = b.occ; d.sky = b.use_sky ? b.sky : nullptr;
   for (int l = 0; l < kMaxLevels; l++) {
     d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l];
     d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
@@ -594,6 +607,11 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "stitch_rounds")) *value = h->stitch_stats[0];      // the last run cutting: pointer-jumping rounds that had work
   else if (!strcmp(name, "stitch_loop_ends")) *value = h->stitch_stats[1];   // ... chain ends on closed loops of paired chains
   else if (!strcmp(name, "debug_run_cap")) *value = h->debug_run_cap;
+  else if (!strcmp(name, "skyline")) *value = h->skyline;
+  else if (!strcmp(name, "skyline_used0") || !strcmp(name, "skyline_used1")) *value = h->bvh[name[12] - '0'].use_sky ? 1 : 0;
+  else if (!strcmp(name, "closed_chains0") || !strcmp(name, "closed_chains1")) *value = (int64_t) h->map[name[13] - '0'].closed_chains;
+  else if (!strcmp(name, "debug_pack_solo")) *value = h->debug_pack_solo;
+  else if (!strcmp(name, "debug_pack_spread")) *value = h->debug_pack_spread;
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
   else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
@@ -619,9 +637,24 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     h->leaf_order = (int) value;
     return RJ_OK;
   }
+  if (!strcmp(name, "debug_pack_solo")) {  // (experiments: runs longer than this keep a leaf to themselves; 0 = the default)
+    if (value < 0 || value > 64) return fail(h, RJ_E_INVALID, "debug_pack_solo: 0..64");
+    h->debug_pack_solo = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "debug_pack_spread")) {  // (experiments: a shared leaf may be this many times as large as its runs; 0 = the default)
+    if (value < 0 || value > 1000000) return fail(h, RJ_E_INVALID, "debug_pack_spread out of range");
+    h->debug_pack_spread = (int) value;
+    return RJ_OK;
+  }
   if (!strcmp(name, "debug_run_cap")) {  // (experiments: edges per polyline run of the NEXT first build of a map; 0 = by the mean chain length)
     if (value != 0 && (value < 2 || value > 64)) return fail(h, RJ_E_INVALID, "debug_run_cap: 0 or 2..64");
     h->debug_run_cap = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "skyline")) {
+    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "skyline: -1 auto (maps of isolated rings), 0 never, 1 always");
+    h->skyline = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "lsi_segments")) {
@@ -689,6 +722,8 @@ int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const
   if (map_id < 0 || map_id > 1) return fail(h, RJ_E_INVALID, "map_id must be 0 or 1");
   RJ_HIP(h, join_aux(h));
   co_reset(h);
+  h->h_rest[0] = h->h_rest[1] = ~0ull;  // (what the last walk over another map left to k_pip says nothing about this one)
+  h->walk_n[0] = h->walk_n[1] = 0;
   if ((np && !xy) || (nc && (!row_index || !left || !right))) return fail(h, RJ_E_INVALID, "null input array");
   if (np >= (1ull << 32) || nc > np) return fail(h, RJ_E_INVALID, "index_t is 32-bit: np < 2^32, nc <= np");
   if (nc && (row_index[0] != 0 || row_index[nc] != np)) return fail(h, RJ_E_INVALID, "row_index must start at 0 and end at np");
@@ -837,13 +872,10 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   // first time an index of this map wants them and kept (a later rebuild only sorts the runs).
   if (h->leaf_order == 1 && m.ne && m.nc < (1ull << 30) && !m.runs_cut) {
     MapState& mm = h->map[base_map_id];
-    // How long a run may be.  A full leaf (64 edges) is right where chains are long: the strip is a piece of one smooth
-    // line.  A polyline stitched from many SHORT chains wiggles through a junction every few edges, its strip is fat,
-    // and where it runs steeply all of its edges overlap in x -- the in-leaf scans (x-sorted slots) then test every
-    // slot.  Half-full leaves of 32 edges measured better there on BOTH kernels (WaterBodies stand-in, 10-edge chains:
-    // k_lsi 1.29 vs 1.49 ms with 64, 1.37 Hilbert; PIP 1.75 vs 1.88 / 1.88) and worse where chains are long (USCounty:
-    // PIP 0.87 vs 0.74): the cap follows the mean chain length.
-    uint32_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
+    // How long a run may be: a full leaf.  (Round 3 cut maps of short chains into runs of 32 -- fat, steep strips whose
+    // edges all overlap in x made the in-leaf scans of 64-edge runs slower on the WaterBodies lattice; with the leaf
+    // scans on the x-bucket table that no longer shows: k_lsi 1.27 ms with 64 against 1.31, the index half the size.)
+    uint32_t cap_edges = 64;
     if (h->debug_run_cap) cap_edges = (uint32_t) h->debug_run_cap;
     uint64_t max_pieces = 0, max_runs = 0;
     stitch_output_bounds(mm.nc, mm.ne, cap_edges, &max_pieces, &max_runs);
@@ -866,12 +898,55 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     mm.nruns = nruns_cut;
     mm.npieces = npieces_cut;
     mm.run_cap = cap_edges;
+    mm.closed_chains = h->stitch_stats[3];
     mm.runs_cut = true;
   }
-  // (a map of short polylines -- polygons of a few edges that touch nothing -- would leave its leaves mostly empty:
-  //  above 2.5 slots per segment the Hilbert leaves are the better index, and smaller)
-  const uint64_t nruns = (h->leaf_order == 1 && m.ne && m.runs_cut && m.nruns * 64 <= m.ne * 5 / 2) ? m.nruns : 0;
-  const uint64_t n0p_new = nruns ? nruns * 64 : pad64(m.ne ? m.ne : 1);
+  // Polyline-run leaves: the runs get a Hilbert key and are sorted FIRST -- consecutive short runs of that order then share
+  // a leaf (k_pack_runs: a map of isolated rings, ten edges per chain, fills its leaves with several neighbouring rings
+  // instead of one ring and 54 empty slots), and the number of leaves sizes everything allocated below.
+  MortonKey *k_in = nullptr, *k_out = nullptr;
+  uint32_t *v_in = nullptr, *v_out = nullptr;
+  uint64_t nruns = (h->leaf_order == 1 && m.ne && m.runs_cut) ? m.nruns : 0;
+  uint64_t nleaves_runs = 0;
+  if (nruns) {
+    MapState& mm = h->map[base_map_id];
+    if (int r = ensure_sort_scratch(h, nruns)) return r;
+    k_in = h->ord_kin; k_out = h->ord_kout; v_in = h->ord_vin; v_out = h->ord_vout;
+    const uint64_t nchunks = pack_runs_chunks(nruns);
+    if (!mm.run_len) {
+      int rc = dev_alloc(h, &mm.run_len, nruns);
+      if (!rc) rc = dev_alloc(h, &mm.leaf_first, nruns + 1);
+      if (!rc) rc = dev_alloc(h, &mm.run_box, nruns);
+      if (!rc) rc = dev_alloc(h, &mm.pack_tmp, 2 * (nchunks + 1));
+      if (rc) return rc;
+    }
+    // a run longer than this keeps its leaf to itself (a nearly full strip of one polyline gains little from a tenant and
+    // its box would have to be computed); a shared leaf may be `spread` times as large as what it holds
+    const uint32_t solo_above = h->debug_pack_solo ? (uint32_t) h->debug_pack_solo : 48;
+    // (measured on the ring-shaped pairs, PIP query alone: 4 / 8 / 16 -> lake-shaped base 40.2 / 41.6 / 41.8 ms, lakes x
+    //  parks 18.7 / 19.7 / 24.2, gaussian polygons 2.46 / 2.25 / 2.18: 8)
+    const uint32_t spread = h->debug_pack_spread ? (uint32_t) h->debug_pack_spread : 8;
+    hipError_t e = hipSuccess;
+    tic(h, RJ_T_BUILD_KEYS);
+    e = launch_run_keys(h->stream, m.seg, m.piece_begin, m.piece_len, m.run_first, nruns, k_in, v_in, mm.run_len, mm.run_box, solo_above);
+    toc(h, RJ_T_BUILD_KEYS);
+    tic(h, RJ_T_BUILD_SORT);
+    size_t tb = h->ord_temp_bytes;
+    if (e == hipSuccess) e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, nruns);
+    if (e == hipSuccess) e = launch_pack_runs(h->stream, v_out, mm.run_len, mm.run_box, nruns, solo_above, spread, mm.pack_tmp, mm.pack_tmp + nchunks + 1, mm.leaf_first, h->d_rest + 3);
+    toc(h, RJ_T_BUILD_SORT);
+    RJ_HIP(h, e);
+    if (!mm.packed_leaves || mm.packed_solo != solo_above + 1000 * spread) {
+      // the first time (the packing is a function of the runs and their order: a rebuild finds the same leaves)
+      RJ_HIP(h, hipStreamSynchronize(h->stream));
+      mm.packed_leaves = h->h_rest[3];
+      mm.packed_solo = solo_above + 1000 * spread;
+    }
+    nleaves_runs = mm.packed_leaves;
+    // (leaves still mostly empty -- cannot happen with runs sharing leaves unless "debug_pack_solo" forbids it: Hilbert leaves)
+    if (nleaves_runs * 64 > m.ne * 5 / 2) nruns = 0;
+  }
+  const uint64_t n0p_new = nruns ? nleaves_runs * 64 : pad64(m.ne ? m.ne : 1);
   if (n0p_new >= (1ull << 32)) return fail(h, RJ_E_INVALID, "rj_build_lbvh: %llu leaf slots do not fit 32-bit slot ids", (unsigned long long) n0p_new);
   const bool reuse = b.sseg && b.n0p == n0p_new;  // rebuild of a same-sized map: keep the buffers
   if (!reuse) free_bvh(b);
@@ -902,32 +977,41 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
     if (!r) r = dev_alloc(h, &b.xtab, b.n0p);
     if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
+    if (!r) r = dev_alloc(h, &b.sky, (uint64_t) kSkyBuckets + 1);  // (1 MiB: allocated with the index, filled when wanted)
     for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l] + b.alloc[l] / 2);  // 16 B box + 8 B order word per node
     if (r) { free_bvh(b); return r; }
   }
-  // 1. Morton keys  2. radix sort (key, eid)  3. leaves + occupancy + level 1 in one pass  4. upper levels
-  if (m.ne)
+  // 1. Morton keys  2. radix sort (key, eid)  (Hilbert leaves; the runs were keyed and sorted above)
+  // 3. leaves + occupancy + level 1 in one pass  4. upper levels
+  if (!nruns && m.ne) {
     if (int r = ensure_sort_scratch(h, m.ne)) return r;
-  MortonKey *k_in = h->ord_kin, *k_out = h->ord_kout;
-  uint32_t *v_in = h->ord_vin, *v_out = h->ord_vout;
+    k_in = h->ord_kin; k_out = h->ord_kout; v_in = h->ord_vin; v_out = h->ord_vout;
+  }
   hipError_t e = hipSuccess;
   do {
-    tic(h, RJ_T_BUILD_KEYS);
-    if (nruns) {
-      if ((e = launch_run_keys(h->stream, m.seg, m.piece_begin, m.piece_len, m.run_first, nruns, k_in, v_in)) != hipSuccess) break;
-    } else if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
-    toc(h, RJ_T_BUILD_KEYS);
-    tic(h, RJ_T_BUILD_SORT);
-    if (m.ne) {
-      size_t tb = h->ord_temp_bytes;
-      if ((e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, nruns ? nruns : m.ne)) != hipSuccess) break;
+    if (!nruns) {
+      tic(h, RJ_T_BUILD_KEYS);
+      if ((e = launch_morton(h->stream, m.seg, m.ne, k_in, v_in)) != hipSuccess) break;
+      toc(h, RJ_T_BUILD_KEYS);
+      tic(h, RJ_T_BUILD_SORT);
+      if (m.ne) {
+        size_t tb = h->ord_temp_bytes;
+        if ((e = sort_morton_pairs(h->stream, h->ord_temp, tb, k_in, k_out, v_in, v_out, m.ne)) != hipSuccess) break;
+      }
+      toc(h, RJ_T_BUILD_SORT);
     }
-    toc(h, RJ_T_BUILD_SORT);
     tic(h, RJ_T_BUILD_LEAVES);
     if ((e = hipMemsetAsync(b.occ, 0, ((size_t) kOccDim * kOccRowWords + 1) * 4, h->stream)) != hipSuccess) break;
+    // The skyline (rj_device.h kSkyShift) is what proves a MISS of the upward ray without a traversal.  A planar subdivision
+    // has an outer boundary over every x it covers -- a ray from inside never misses, the table would cost the build up
+    // to a third of its time (one atomic per segment and bucket) and every query point a load for nothing; a map of
+    // isolated rings leaves a third of a lattice's vertices with nothing above them (35 % measured on the lake-shaped
+    // stand-in, 240 leaf blocks opened for each).  So: built where most chains are closed rings.
+    b.use_sky = h->skyline == 1 || (h->skyline < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc);
+    if (b.use_sky && (e = hipMemsetAsync(b.sky, 0, ((size_t) kSkyBuckets + 1) * 4, h->stream)) != hipSuccess) break;
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, nruns ? m.piece_begin : nullptr,
-                                 m.piece_len, m.run_first, b.n0p / 64, b.alloc[1],
-                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ)) != hipSuccess) break;
+                                 m.piece_len, m.run_first, m.leaf_first, b.n0p / 64, b.alloc[1],
+                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ, b.use_sky ? b.sky : nullptr)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
     const QBox* child = b.lvl[1];
@@ -948,6 +1032,8 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   RJ_HIP(h, e);
   b.built = true;
   co_reset(h);
+  h->h_rest[0] = h->h_rest[1] = ~0ull;  // (a new index: the "auto" decision to drop the walk is taken again)
+  h->walk_n[0] = h->walk_n[1] = 0;
   return RJ_OK;
 }
 
@@ -1944,6 +2030,12 @@ int rj_last_ms(rj_handle h, int which, float* ms) {
   if (which < 0 || which >= kNumTimers || !ms) return fail(h, RJ_E_INVALID, "rj_last_ms: bad timer");
   if (!h->ev_valid[which]) return fail(h, RJ_E_INVALID, "rj_last_ms: stage %d has not run", which);
   if (int r = set_device(h)) return r;
+  if (timers_off(h)) {
+    // ("timers" 0: the last query recorded nothing -- the time is an earlier query's; what the header promises of this
+    //  call, that the stage's outputs are complete when it returns, is kept by waiting for the streams themselves)
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    RJ_HIP(h, join_aux(h));
+  }
   RJ_HIP(h, hipEventSynchronize(h->ev[which][1]));
   RJ_HIP(h, hipEventElapsedTime(ms, h->ev[which][0], h->ev[which][1]));
   return RJ_OK;

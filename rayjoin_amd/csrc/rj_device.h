@@ -45,7 +45,16 @@ constexpr int64_t kCoordOffset = (int64_t) 1 << 46;
 constexpr int kOccShift = 19;                  // 31-bit quantised coordinate -> 12-bit cell
 constexpr int kOccDim = 1 << (31 - kOccShift);  // 4096 x 4096 cells = 2 MiB of bits
 constexpr int kOccRowWords = kOccDim / 32;
-constexpr int kOccMaxCellsPerSeg = 4096;  // larger boxes are not rasterised; word [kOccDim*kOccRowWords] flags that
+constexpr int kOccMaxCellsPerSeg = 4096;
+// The SKYLINE of an indexed map (round 4): per x-bucket of 2^kSkyShift quanta, 1 + the highest quantised y of any
+// segment whose box touches the bucket (0: none does).  A query point that lies above it has NO edge above itself --
+// a certain miss of the upward ray, answered without a traversal.  Proving a miss is the one thing a box hierarchy is
+// bad at (every box over the column has to be opened: 35 % of a lattice's vertices against a lake-shaped base map,
+// 240 leaf blocks each); here it is one 4-byte load.  Word [kSkyBuckets] = 1 when some segment was too wide to
+// register (the table is then not exhaustive and the kernels ignore it).
+constexpr int kSkyShift = 13;
+constexpr int kSkyBuckets = 1 << (31 - kSkyShift);  // 262 144 words = 1 MiB
+constexpr int kSkyMaxSpan = 2048;                   // buckets one segment may raise  // larger boxes are not rasterised; word [kOccDim*kOccRowWords] flags that
 // Morton keys keep only their top 32 bits (16 per axis over the scaled +-2^46 domain; the reference's
 // codes have 10 per axis, deps/lbvh/lbvh/morton_code.cuh:23-35): finer bits do not change tree
 // quality -- ties keep eid order = chain order, the sort is stable -- and a 32-bit key sorts in 4
@@ -81,6 +90,7 @@ struct DeviceBvh {
                           // bucket starts below this slot), .y byte k = slots whose prefix-max x1 ends before the bucket
                           // (where the scan stops): the candidates of a point, without a search and without a stop test
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
+  const uint32_t* sky;    // skyline, kSkyBuckets + 1 words (see kSkyShift); nullable
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
   // Behind the boxes of every level l (at lvl[l] + pad64(nlvl[l])) sits one 64-bit word per node:
   // bit k set = sibling k (same 64-entry group) lies HIGHER (box centre, ties by index) -- the

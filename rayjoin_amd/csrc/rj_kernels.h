@@ -126,14 +126,18 @@ hipError_t warm_stitch_kernels(hipStream_t st);
 void stitch_output_bounds(uint64_t nc, uint64_t ne, uint32_t cap, uint64_t* max_pieces, uint64_t* max_runs);
 hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin, uint64_t nc, uint64_t ne, uint32_t cap,
                               uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first, uint64_t* nruns, uint64_t* npieces,
-                              uint32_t* stats /* [3] nullable: ranking rounds, incidences on closed loops, rounds of the second ranking */);
+                              uint32_t* stats /* [4] nullable: ranking rounds, incidences on closed loops, rounds of the second ranking, closed chains */);
 hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* piece_begin, const uint32_t* piece_len, const uint32_t* run_first,
-                           uint64_t nruns, MortonKey* keys, uint32_t* vals);
+                           uint64_t nruns, MortonKey* keys, uint32_t* vals, uint32_t* run_len, QBox* run_box, uint32_t box_upto);
+uint64_t pack_runs_chunks(uint64_t nruns);
+hipError_t launch_pack_runs(hipStream_t st, const uint32_t* order, const uint32_t* run_len, const QBox* run_box, uint64_t nruns,
+                            uint32_t solo_above, uint32_t spread, uint32_t* chunk_leaves, uint32_t* chunk_base, uint32_t* leaf_first,
+                            unsigned long long* total_out);
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
-                               const uint32_t* piece_len, const uint32_t* run_first, uint64_t nblocks,
+                               const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ);
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, uint32_t* sky);
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);

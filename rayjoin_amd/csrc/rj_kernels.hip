@@ -102,14 +102,124 @@ __global__ __launch_bounds__(256) void k_morton(const Seg* __restrict__ seg, uin
 // Polyline-run leaves: the sort key of a run = the Hilbert key of the midpoint of the middle edge of its middle piece
 __global__ __launch_bounds__(256) void k_run_keys(const Seg* __restrict__ seg, const uint32_t* __restrict__ piece_begin,
                                                   const uint32_t* __restrict__ piece_len, const uint32_t* __restrict__ run_first,
-                                                  uint64_t nruns, MortonKey* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                  uint64_t nruns, MortonKey* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                  uint32_t* __restrict__ run_len, QBox* __restrict__ run_box, uint32_t box_upto) {
   for (uint64_t r = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; r < nruns; r += (uint64_t) gridDim.x * blockDim.x) {
-    const uint32_t p = (run_first[r] + run_first[r + 1]) >> 1;
+    const uint32_t p0 = run_first[r], p1 = run_first[r + 1];
+    const uint32_t p = (p0 + p1) >> 1;
     const Seg s = seg[piece_begin[p] + (piece_len[p] >> 1)];
     const uint64_t mx = (uint64_t) (((s.x1 + s.x2) >> 1) + kCoordOffset), my = (uint64_t) (((s.y1 + s.y2) >> 1) + kCoordOffset);
     keys[r] = (MortonKey) hilbert16((uint32_t) (mx >> 31), (uint32_t) (my >> 31));
     vals[r] = (uint32_t) r;
+    uint32_t len = 0;
+    for (uint32_t q = p0; q < p1; q++) len += piece_len[q];
+    run_len[r] = len;
+    // the box of a SHORT run (one that may share a leaf, k_pack_runs): the vertices of its pieces
+    QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
+    if (len <= box_upto) {
+      for (uint32_t q = p0; q < p1; q++) {
+        const uint32_t e0 = piece_begin[q], n = piece_len[q];
+        for (uint32_t k = 0; k < n; k++) {
+          const Seg t = seg[e0 + k];
+          const int32_t ax = quant(t.x1), ay = quant(t.y1), bx = quant(t.x2), by = quant(t.y2);
+          b.x0 = min(b.x0, min(ax, bx)); b.y0 = min(b.y0, min(ay, by));
+          b.x1 = max(b.x1, max(ax, bx)); b.y1 = max(b.y1, max(ay, by));
+        }
+      }
+    }
+    run_box[r] = b;
   }
+}
+
+// Leaves of SEVERAL runs (round 4).  A map of isolated rings -- lakes, parks: ten edges per chain, nothing to stitch --
+// has runs far shorter than a leaf; one leaf per run would be mostly padding (> 2.5 slots per segment: the build used to
+// fall back to Hilbert leaves there).  Consecutive runs of the Hilbert-sorted order share a leaf while they fit its 64
+// slots; a run is never split, and a run longer than `solo_above` edges keeps a leaf to itself (a strip of one
+// polyline is what makes a leaf thin).  Greedy along the sorted order, in independent chunks of kPackChunk runs (a
+// chunk starts a new leaf: one part-filled leaf per 256 runs is the price of not being sequential): pass 1 counts
+// the leaves of every chunk, a scan places the chunks, pass 2 writes where every leaf starts.
+constexpr uint32_t kPackChunk = 256;
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_pack_runs(const uint32_t* __restrict__ order, const uint32_t* __restrict__ run_len,
+                                                   const QBox* __restrict__ run_box, uint64_t nruns,
+                                                   uint32_t solo_above, uint32_t spread, uint32_t* __restrict__ chunk_leaves,
+                                                   const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ leaf_first) {
+  const uint64_t nchunks = (nruns + kPackChunk - 1) / kPackChunk;
+  for (uint64_t c = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; c < nchunks; c += (uint64_t) gridDim.x * blockDim.x) {
+    const uint64_t j0 = c * kPackChunk, j1 = j0 + kPackChunk < nruns ? j0 + kPackChunk : nruns;
+    uint32_t cur = 0, leaves = 0;
+    bool closed = false;
+    QBox u = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
+    uint64_t own = 0;  // sum of the half-perimeters of the runs in the leaf
+    const uint32_t base = WRITE ? chunk_base[c] : 0;
+    for (uint64_t j = j0; j < j1; j++) {
+      const uint32_t r = order[j];
+      const uint32_t len = run_len[r];
+      const bool solo = len > solo_above;
+      bool join = cur != 0 && !closed && !solo && cur + len <= 64;
+      QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax}, v = u;
+      uint64_t hp = 0;
+      if (!solo) {
+        b = run_box[r];
+        hp = (uint64_t) (b.x1 - b.x0) + (uint64_t) (b.y1 - b.y0) + 2;
+      }
+      if (join) {
+        // ... and only while the leaf stays about as large as what it holds: where the sorted order jumps -- the curve
+        // leaving one cluster of rings for the next -- a shared leaf would be a box across the gap that every ray
+        // through the gap has to open (measured on the lake-shaped stand-in: 650 leaf visits per 64 points)
+        v.x0 = min(u.x0, b.x0); v.y0 = min(u.y0, b.y0); v.x1 = max(u.x1, b.x1); v.y1 = max(u.y1, b.y1);
+        const uint64_t uhp = (uint64_t) (v.x1 - v.x0) + (uint64_t) (v.y1 - v.y0);
+        join = uhp <= (uint64_t) spread * (own + hp);
+      }
+      if (join) {
+        cur += len;
+        u = v;
+        own += hp;
+      } else {
+        if (WRITE) leaf_first[base + leaves] = (uint32_t) j;
+        leaves++;
+        cur = len;
+        closed = solo;
+        u = b;
+        own = hp;
+      }
+    }
+    if (!WRITE) chunk_leaves[c] = leaves;
+  }
+}
+// exclusive scan of n counts by ONE block (n = runs / 256: tens of thousands at most), the total behind the last entry
+// and, for the host, in *total_out (mapped or device memory)
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                                                      unsigned long long* __restrict__ total_out) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint64_t b = 0; b < n; b += 1024) {
+    const uint64_t i = b + threadIdx.x;
+    const uint32_t v = i < n ? in[i] : 0;
+    uint32_t inc = v;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t t = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += t;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t before = carry;
+    for (int k = 0; k < w; k++) before += wsum[k];
+    if (i < n) out[i] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[n] = carry;
+    *total_out = carry;
+  }
+}
+__global__ void k_pack_end(uint32_t* __restrict__ leaf_first, const uint32_t* __restrict__ chunk_base, uint64_t nchunks, uint32_t nruns) {
+  leaf_first[chunk_base[nchunks]] = nruns;  // the sentinel behind the last leaf
 }
 
 // Occupancy bitmap of the indexed map: every cell a segment's quantised box touches is set.
@@ -203,11 +313,13 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       const uint32_t* __restrict__ piece_begin,
                                                       const uint32_t* __restrict__ piece_len,
                                                       const uint32_t* __restrict__ run_first,
+                                                      const uint32_t* __restrict__ leaf_first,
                                                       uint64_t nblocks, uint64_t n_parent_alloc,
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
                                                       int32_t* __restrict__ pmx1, uint2* __restrict__ xtab,
-                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ) {
+                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ,
+                                                      uint32_t* __restrict__ sky) {
   __shared__ int32_t sx1[4][64];
   __shared__ uint4 hist[4][64];  // 256 x-bucket counters per wave
   const int lane = lane_id();
@@ -225,19 +337,22 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     uint32_t id = 0xFFFFFFFFu;
     int32_t fc = 0;
     // Hilbert leaves: the block's segments are 64 neighbours of the sorted order.  Polyline-run leaves ("leaf_order" 1):
-    // the block is one run (<= 64 edges in a few pieces: eid ranges of the chains the polyline crosses), `order` sorts the runs.
+    // the block is one run (<= 64 edges in a few pieces: eid ranges of the chains the polyline crosses) or a few short runs
+    // that follow each other in the sorted order (`order` sorts the runs, leaf_first[blk] is the block's first).
     bool valid = i < ne;
     if (piece_begin) {
-      const uint32_t r = order[blk];
       valid = false;
       uint32_t acc = 0;
-      for (uint32_t p = run_first[r]; p < run_first[r + 1]; p++) {  // (wave-uniform bounds and loads; a handful of pieces)
-        const uint32_t len = piece_len[p];
-        if (!valid && (uint32_t) lane < acc + len) {
-          valid = true;
-          id = piece_begin[p] + ((uint32_t) lane - acc);
+      for (uint32_t j = leaf_first[blk]; j < leaf_first[blk + 1]; j++) {  // the leaf's runs (k_pack_runs): one, or a few short ones
+        const uint32_t r = order[j];
+        for (uint32_t p = run_first[r]; p < run_first[r + 1]; p++) {  // (wave-uniform bounds and loads; a handful of pieces)
+          const uint32_t len = piece_len[p];
+          if (!valid && (uint32_t) lane < acc + len) {
+            valid = true;
+            id = piece_begin[p] + ((uint32_t) lane - acc);
+          }
+          acc += len;
         }
-        acc += len;
       }
     } else if (valid) {
       id = __builtin_nontemporal_load(&order[i]);
@@ -252,6 +367,16 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
       b.y1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
     }
     mark_occupancy_wave(b, valid, occ, lane);
+    if (valid && sky) {  // the skyline (maps of isolated rings only): every x-bucket the segment's box touches is at least this high
+      const int k0 = b.x0 >> kSkyShift, k1 = b.x1 >> kSkyShift;
+      const uint32_t top = (uint32_t) b.y1 + 1u;
+      if (k1 - k0 >= kSkyMaxSpan) {
+        sky[kSkyBuckets] = 1u;
+      } else {
+        for (int k = k0; k <= k1; k++)  // (neighbours in a leaf raise the same buckets: look before paying an atomic)
+          if (__hip_atomic_load(&sky[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < top) atomicMax(&sky[k], top);
+      }
+    }
     int rank = 0;
     for (int k = 0; k < 64; k++) {
       const int32_t xk = bcast(b.x0, k);
@@ -355,6 +480,12 @@ __global__ __launch_bounds__(256) void k_sibling_order(const QBox* __restrict__ 
     }
     higher[g * 64 + lane] = m;
   }
+}
+
+// the upward ray from the quantised point (qx, qy) can meet something: some segment over its x-bucket reaches its height
+// (see kSkyShift; `sky` null or not exhaustive: cannot tell)
+__device__ __forceinline__ bool ray_has_sky(const uint32_t* __restrict__ sky, int32_t qx, int32_t qy) {
+  return !sky || sky[(uint32_t) qx >> kSkyShift] > (uint32_t) qy;
 }
 
 // number of lanes j with v[j] <= key, for v non-decreasing over the 64 lanes (lane j holds v[j]).
@@ -1159,6 +1290,7 @@ __device__ __forceinline__ void pip_locate(const PipArgs& A, const uint32_t bid,
   }
   const uint64_t ngroups = (nq + GL - 1) / GL;
   const DeviceBvh& T = A.bvh;
+  const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;  // (exhaustive, or not used)
   const int qm = A.query_map_id;
   const int stack_cap = STATS && A.stack_cap < kPipStack ? A.stack_cap : kPipStack;  // (lowered only by tests of the fault path, instrumented kernel)
   unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
@@ -1191,13 +1323,15 @@ __device__ __forceinline__ void pip_locate(const PipArgs& A, const uint32_t bid,
       qx = quant(A.pts[2 * ip]);
       qy = quant(A.pts[2 * ip + 1]);
     }
+    // (a point above the skyline of the map has nothing above it: a miss, without a traversal -- it sits the group out)
+    const bool live = valid && ray_has_sky(sky, qx, qy);
     const int32_t qym1 = qy > 0 ? qy - 1 : 0;
-    const int32_t gx0 = wave_min(valid ? qx : kEmptyMin);
-    const int32_t gx1 = wave_max(valid ? qx : kEmptyMax);
-    const int32_t gy0 = wave_min(valid ? qy : kEmptyMin);
+    const int32_t gx0 = wave_min(live ? qx : kEmptyMin);
+    const int32_t gx1 = wave_max(live ? qx : kEmptyMax);
+    const int32_t gy0 = wave_min(live ? qy : kEmptyMin);
     double best_yy = __builtin_inf();
     uint32_t best_slot = 0xFFFFFFFFu;  // sorted slot of the best edge so far (eid/face are looked up at the end)
-    int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer
+    int32_t qbest = live ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer
     int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
     int cnt = 0;                              // this lane's candidate-list fill
     bool sure1 = false;  // the list holds exactly one candidate and it is a certain hit
@@ -1449,6 +1583,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const DeviceBvh& T = A.bvh;
+  const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;  // (exhaustive, or not used)
   const int stack_cap = walk_stack_entries(T.top);
   uint4* const stack = walk_smem + (size_t) wib * (walk_wave_lds(T.top) / 16);
   uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [kWalkList][64], bank = lane
@@ -1481,10 +1616,11 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
       qx = quant(p.x);
       qy = quant(p.y);
     }
+    const bool live = valid && ray_has_sky(sky, qx, qy);  // (above the map's skyline: a certain miss, no traversal)
     const int32_t qym1 = qy > 0 ? qy - 1 : 0;
-    int32_t gx0 = valid ? qx : kEmptyMin, gx1 = valid ? qx : kEmptyMax, gy0 = valid ? qy : kEmptyMin;
+    int32_t gx0 = live ? qx : kEmptyMin, gx1 = live ? qx : kEmptyMax, gy0 = live ? qy : kEmptyMin;
     wave_min_max_min(gx0, gx1, gy0);
-    int32_t qbest = valid ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer (-1: the lane sits out)
+    int32_t qbest = live ? 0x7FFFFFFF : -1;  // sound quantised upper bound of this lane's answer (-1: the lane sits out)
     int32_t gbest = 0x7FFFFFFF;               // wave max of qbest
     // This lane's candidate list is cand[lane + 64 k] (bank = lane); `cand_at` = where the next one goes, so the fill
     // is (cand_at - lane) / 64 and kWalkList + 1 fills mean "overflowed: the rest list takes the point".
@@ -1698,6 +1834,7 @@ __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const DeviceBvh& T = A.bvh;
+  const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;  // (exhaustive, or not used)
   const int stack_cap = walk_stack_entries(T.top);
   uint4* const stack = walk_smem + (size_t) wib * (walk2_wave_lds(T.top) / 16);
   uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [2][LIST][64], bank = lane
@@ -1734,11 +1871,18 @@ __global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
       cand_at[p] = cand_base[p];
       sure_y0[p] = INT32_MIN;
     }
+    // (above the map's skyline: a certain miss -- the point sits the traversal out like a position past the end)
+    if (sky) {
+#pragma unroll
+      for (int p = 0; p < 2; p++)
+        if (sky[(uint32_t) qx[p] >> kSkyShift] <= (uint32_t) qy[p]) qbest[p] = -1;
+    }
     int32_t gx0, gx1, gy0;
     {
-      const int32_t a0 = valid[0] ? qx[0] : kEmptyMin, a1 = valid[1] ? qx[1] : kEmptyMin;
-      const int32_t b0 = valid[0] ? qx[0] : kEmptyMax, b1 = valid[1] ? qx[1] : kEmptyMax;
-      const int32_t c0 = valid[0] ? qy[0] : kEmptyMin, c1 = valid[1] ? qy[1] : kEmptyMin;
+      const bool l0 = qbest[0] >= 0, l1 = qbest[1] >= 0;
+      const int32_t a0 = l0 ? qx[0] : kEmptyMin, a1 = l1 ? qx[1] : kEmptyMin;
+      const int32_t b0 = l0 ? qx[0] : kEmptyMax, b1 = l1 ? qx[1] : kEmptyMax;
+      const int32_t c0 = l0 ? qy[0] : kEmptyMin, c1 = l1 ? qy[1] : kEmptyMin;
       gx0 = a0 < a1 ? a0 : a1; gx1 = b0 > b1 ? b0 : b1; gy0 = c0 < c1 ? c0 : c1;
     }
     wave_min_max_min(gx0, gx1, gy0);
@@ -2068,19 +2212,38 @@ hipError_t launch_swap_halves(hipStream_t st, uint64_t* v, uint64_t n) {
 }
 
 hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* piece_begin, const uint32_t* piece_len, const uint32_t* run_first,
-                           uint64_t nruns, MortonKey* keys, uint32_t* vals) {
+                           uint64_t nruns, MortonKey* keys, uint32_t* vals, uint32_t* run_len, QBox* run_box, uint32_t box_upto) {
   if (nruns == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_run_keys, dim3(grid_for(nruns, 256, 8192)), dim3(256), 0, st, seg, piece_begin, piece_len, run_first, nruns, keys, vals);
+  hipLaunchKernelGGL(k_run_keys, dim3(grid_for(nruns, 256, 8192)), dim3(256), 0, st, seg, piece_begin, piece_len, run_first, nruns, keys, vals,
+                     run_len, run_box, box_upto);
+  return hipGetLastError();
+}
+
+uint64_t pack_runs_chunks(uint64_t nruns) { return (nruns + kPackChunk - 1) / kPackChunk; }
+// order[nruns] (sorted run ids), run_len / run_box[nruns] -> leaf_first[leaves + 1]; chunk_leaves / chunk_base: scratch of
+// pack_runs_chunks(nruns) + 1 words each; *total_out = the number of leaves (written on the stream)
+hipError_t launch_pack_runs(hipStream_t st, const uint32_t* order, const uint32_t* run_len, const QBox* run_box, uint64_t nruns,
+                            uint32_t solo_above, uint32_t spread, uint32_t* chunk_leaves, uint32_t* chunk_base, uint32_t* leaf_first,
+                            unsigned long long* total_out) {
+  if (nruns == 0) return hipSuccess;
+  const uint64_t nchunks = pack_runs_chunks(nruns);
+  const int grid = grid_for(nchunks, 256, 4096);
+  hipLaunchKernelGGL(k_pack_runs<false>, dim3(grid), dim3(256), 0, st, order, run_len, run_box, nruns, solo_above, spread, chunk_leaves,
+                     (const uint32_t*) nullptr, (uint32_t*) nullptr);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, chunk_leaves, chunk_base, nchunks, total_out);
+  hipLaunchKernelGGL(k_pack_runs<true>, dim3(grid), dim3(256), 0, st, order, run_len, run_box, nruns, solo_above, spread, (uint32_t*) nullptr,
+                     chunk_base, leaf_first);
+  hipLaunchKernelGGL(k_pack_end, dim3(1), dim3(1), 0, st, leaf_first, chunk_base, nchunks, (uint32_t) nruns);
   return hipGetLastError();
 }
 
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
-                               const uint32_t* piece_len, const uint32_t* run_first, uint64_t nblocks,
+                               const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ) {
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, uint32_t* sky) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, piece_begin, piece_len, run_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
+                     left, right, ne, piece_begin, piece_len, run_first, leaf_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ, sky);
   return hipGetLastError();
 }
 

@@ -68,13 +68,15 @@ struct Meta {
   uint32_t act2[kMaxRounds];  // the same for the second ranking (after the loops were opened)
   uint32_t done_round2;
   uint32_t nruns, npieces;    // totals (chain_emit)
+  uint32_t closed_chains;     // chains that start and end on the same point (rings): end_keys
 };
 
 RJ_SHD uint32_t chain_len(const uint32_t* eb, uint32_t c) { return eb[c + 1] - eb[c]; }
 
 // ---- 1. the ends of the chains ------------------------------------------------------------------
 // incidence i = 2 c + end (0: the chain's first point, 1: its last); point indices of chain c: eb[c] + c .. eb[c + 1] + c
-RJ_SHD void end_keys(uint32_t i, const int64_t* pts, const uint32_t* eb, uint64_t* kx, uint64_t* ky, Dir* dir) {
+// -> true for the first incidence of a closed chain (the caller counts the rings of the map)
+RJ_SHD bool end_keys(uint32_t i, const int64_t* pts, const uint32_t* eb, uint64_t* kx, uint64_t* ky, Dir* dir) {
   const uint32_t c = i >> 1;
   const uint64_t p0 = (uint64_t) eb[c] + c, p1 = (uint64_t) eb[c + 1] + c;
   const uint64_t p = (i & 1) ? p1 : p0, q = (i & 1) ? p1 - 1 : p0 + 1;  // q: the vertex next to this end, inside the chain
@@ -90,6 +92,7 @@ RJ_SHD void end_keys(uint32_t i, const int64_t* pts, const uint32_t* eb, uint64_
   const bool valid = !closed && !(d.x == 0.0f && d.y == 0.0f);
   kx[i] = valid ? (uint64_t) (x + kKeyOffset) : kNoKey;
   ky[i] = valid ? (uint64_t) (y + kKeyOffset) : kNoKey;
+  return closed && !(i & 1);
 }
 
 // ---- 2. junctions --------------------------------------------------------------------------------

@@ -26,10 +26,20 @@ inline int blocks_for(uint64_t n) {
 
 __global__ __launch_bounds__(kThreads) void k_st_end_keys(uint32_t ni, const int64_t* __restrict__ pts, const uint32_t* __restrict__ eb,
                                                           uint64_t* __restrict__ kx, uint64_t* __restrict__ ky, Dir* __restrict__ dir,
-                                                          uint32_t* __restrict__ iota) {
+                                                          uint32_t* __restrict__ iota, Meta* meta) {
+  uint32_t rings = 0;
   RJ_GRID_STRIDE(i, ni) {
-    end_keys((uint32_t) i, pts, eb, kx, ky, dir);
+    rings += end_keys((uint32_t) i, pts, eb, kx, ky, dir) ? 1u : 0u;
     iota[i] = (uint32_t) i;
+  }
+  __shared__ uint32_t part[kThreads / 64];
+  for (int d = 32; d >= 1; d >>= 1) rings += __shfl_down(rings, d, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = rings;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t sum = 0;
+    for (int w = 0; w < kThreads / 64; w++) sum += part[w];
+    if (sum) atomicAdd(&meta->closed_chains, sum);
   }
 }
 __global__ __launch_bounds__(kThreads) void k_st_gather_keys(uint32_t ni, const uint64_t* __restrict__ kx, const uint32_t* __restrict__ sv,
@@ -140,7 +150,7 @@ hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t
                               uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first, uint64_t* nruns, uint64_t* npieces,
                               uint32_t* stats) {
   *nruns = *npieces = 0;
-  if (stats) stats[0] = stats[1] = stats[2] = 0;
+  if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
   if (nc64 == 0) return hipMemsetAsync(run_first, 0, 4, st);
   if (nc64 >= (1ull << 30) || cap == 0) return hipErrorInvalidValue;  // (path keys are 2 bits wider than chain ids)
   const uint32_t nc = (uint32_t) nc64, ni = 2 * nc;
@@ -195,7 +205,7 @@ hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t
     if ((e = hipMemsetAsync(partner, 0xFF, 4 * (size_t) ni, st)) != hipSuccess) break;
     if ((e = hipMemsetAsync(in_loop, 0, nc, st)) != hipSuccess) break;
     // 1. end points -> keys; 2. sort by y, then stably by x; pair every junction
-    hipLaunchKernelGGL(k_st_end_keys, dim3(B), dim3(kThreads), 0, st, ni, pts, eb, kx, ky, dir, va);
+    hipLaunchKernelGGL(k_st_end_keys, dim3(B > 2048 ? 2048 : B), dim3(kThreads), 0, st, ni, pts, eb, kx, ky, dir, va, meta);
     size_t tb = temp_bytes;
     if ((e = rocprim::radix_sort_pairs(temp, tb, ky, ska, va, vb, (size_t) ni, 0, kKeyBits, st)) != hipSuccess) break;
     hipLaunchKernelGGL(k_st_gather_keys, dim3(B), dim3(kThreads), 0, st, ni, kx, vb, skb);
@@ -211,7 +221,7 @@ hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t
     if ((e = hipMemcpyAsync(&hm, meta, sizeof(Meta), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) break;
     const uint32_t on_loops = hm.done_round ? hm.act[hm.done_round - 1] : 0;
-    if (stats) { stats[0] = hm.done_round; stats[1] = on_loops; }
+    if (stats) { stats[0] = hm.done_round; stats[1] = on_loops; stats[3] = hm.closed_chains; }
     int second = 0;
     if (on_loops) {
       // 3b. closed loops of paired chains (rare): find each loop's smallest incidence, open the loop there, rank again

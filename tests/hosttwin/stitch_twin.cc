@@ -166,17 +166,19 @@ int stitch_ref(const int64_t* xy, const uint32_t* eb, uint64_t nc, uint64_t cap,
 }
 
 // the twin of rj_stitch.hip's stitch_runs_device(): same stages, same order; stats[0] = ranking rounds run,
-// stats[1] = incidences on closed loops, stats[2] = rounds of the second ranking
+// stats[1] = incidences on closed loops, stats[2] = rounds of the second ranking, stats[3] = closed chains (rings)
 int stitch_twin(const int64_t* pts, const uint32_t* eb, uint64_t nc64, uint64_t cap64, uint32_t* piece_begin, uint32_t* piece_len,
                 uint32_t* run_first, uint64_t* nruns, uint64_t* npieces, uint64_t* stats) {
   const uint32_t nc = (uint32_t) nc64, cap = (uint32_t) cap64, ni = 2 * nc;
   *nruns = *npieces = 0;
   run_first[0] = 0;
-  if (stats) stats[0] = stats[1] = stats[2] = 0;
+  if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
   if (!nc) return 0;
   std::vector<uint64_t> kx(ni), ky(ni);
   std::vector<Dir> dir(ni);
-  for (uint32_t i = 0; i < ni; i++) end_keys(i, pts, eb, kx.data(), ky.data(), dir.data());
+  uint64_t rings = 0;
+  for (uint32_t i = 0; i < ni; i++) rings += end_keys(i, pts, eb, kx.data(), ky.data(), dir.data()) ? 1 : 0;
+  if (stats) stats[3] = rings;
   // sort by y, then stably by x (two stable radix sorts on the device)
   std::vector<uint32_t> sv(ni);
   std::iota(sv.begin(), sv.end(), 0u);

@@ -77,22 +77,35 @@ def test_both_leaf_orders_equal_the_oracle(oracle, shape):
         h.close()
 
 
-def test_unrelated_short_chains_fall_back_to_hilbert_leaves(oracle):
-    """Polygons of a few edges in random file order (the reference's gaussian workload): a leaf per chain would be
-    mostly padding, a leaf of file neighbours would span the map -- the build keeps the Hilbert leaves."""
-    g = synth.gaussian_polygons(400, 5)
-    ctx = maps.Context([g, synth.lattice_map(8, 20, 27)]).load()
-    m = ctx.maps
-    h = _capi.Handle(0)
-    try:
-        for i in (0, 1):
-            h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
-        h.set_option("leaf_order", 1)
-        h.build_lbvh(0)
-        assert h.get_option("leaf_order_used0") == 0 and h.get_option("leaf_slots0") < m[0].n_edges + 64
+def test_short_rings_share_leaves(oracle):
+    """Polygons of a few edges in random file order (the reference's gaussian workload) and lake-shaped rings: a leaf per
+    ring would be mostly padding (rounds 2-3 fell back to Hilbert leaves there), a leaf of FILE neighbours would span the
+    map -- neighbouring rings of the Hilbert-sorted order share a leaf instead (k_pack_runs): polyline-run leaves, nearly
+    full, every result the oracle's; with sharing forbidden ("debug_pack_solo" 1) the build still falls back."""
+    for g, what in ((synth.gaussian_polygons(4000, 5), "gaussian"), (synth.ring_map(3000, 33000, 7), "rings")):
+        ctx = maps.Context([g, synth.lattice_map(8, 20, 27)]).load()
+        m = ctx.maps
         om = [_omap(oracle, m[0]), _omap(oracle, m[1])]
-        closest = h.alloc(4 * m[1].n_points)
-        h.pip_query(0, 1, None, 0, m[1].n_points, closest, None)
-        assert np.array_equal(closest.to_host(np.uint32), oracle.pip_grid(om[0], 0, m[1].pts, 128))
-    finally:
-        h.close()
+        want_pairs = oracle.lsi_grid(om[0], om[1], 128)["eid"]
+        want_e = oracle.pip_grid(om[0], 0, m[1].pts, 128)
+        h = _capi.Handle(0)
+        try:
+            for i in (0, 1):
+                h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
+            # (sharing whatever the gaps -- nearly full leaves; the default rule -- a shared leaf at most 4 x as large as
+            #  what it holds: full where the rings are dense, one ring per leaf or the Hilbert fall-back where they are
+            #  far apart; sharing forbidden -- the fall-back)
+            for solo, spread, used in ((0, 1000, 1), (0, 0, None), (1, 0, 0)):
+                h.set_option("leaf_order", 1)
+                h.set_option("debug_pack_solo", solo)
+                h.set_option("debug_pack_spread", spread)
+                pairs, closest, face = _run(h, 0, m[1], 8 * len(want_pairs) + 1024)
+                if used is not None:
+                    assert h.get_option("leaf_order_used0") == used, (what, solo, spread)
+                if used:
+                    assert h.get_option("leaf_slots0") <= 1.3 * m[0].n_edges + 64, (what, h.get_option("leaf_slots0"), m[0].n_edges)
+                assert np.array_equal(pairs, want_pairs), (what, solo, spread)
+                assert np.array_equal(closest, want_e), (what, solo, spread)
+                assert np.array_equal(face, om[0].face_ids(want_e)), (what, solo, spread)
+        finally:
+            h.close()

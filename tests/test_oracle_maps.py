@@ -86,3 +86,41 @@ def test_reference_wrap_regime_documented(oracle):
     gr = oracle.lsi_grid(m0, m1, 64)
     assert len(gr) < len(brute)
     assert set(map(tuple, gr["eid"].tolist())) <= set(map(tuple, brute.tolist()))
+
+
+def test_ring_map_is_isolated_disjoint_rings():
+    """synth.ring_map (the lake-shaped stand-ins): every chain is a closed ring, rings are simple (star-shaped) and
+    pairwise disjoint (bounding boxes do not even touch), edge counts are heavy-tailed with the requested mean, the
+    big rings are big -- and two such maps with different seeds do cross each other."""
+    from rayjoin_amd import synth
+    g = synth.ring_map(1500, 1500 * 12, 3, big_share=0.01)
+    ri = g.row_index.astype(np.int64)
+    P = g.points
+    assert g.n_chains == 1500 and abs(g.n_edges / g.n_chains - 12) < 1.0
+    assert np.array_equal(P[ri[:-1]], P[ri[1:] - 1])                      # closed
+    nv = np.diff(ri) - 1
+    assert nv.min() >= 3 and nv.max() > 8 * np.median(nv)                 # heavy tail
+    lo = np.array([P[a:b].min(axis=0) for a, b in zip(ri[:-1], ri[1:])])
+    hi = np.array([P[a:b].max(axis=0) for a, b in zip(ri[:-1], ri[1:])])
+    apart = (lo[:, None, 0] > hi[None, :, 0]) | (hi[:, None, 0] < lo[None, :, 0]) | (lo[:, None, 1] > hi[None, :, 1]) | (hi[:, None, 1] < lo[None, :, 1])
+    np.fill_diagonal(apart, True)
+    assert apart.all()                                                    # disjoint boxes: disjoint rings
+    size = (hi - lo).max(axis=1)
+    assert np.corrcoef(np.log(nv), np.log(size))[0, 1] > 0.3              # more edges, larger ring
+    # star-shaped around the box centre: the vertices' angles around it are monotone (one wrap)
+    for c in (0, int(np.argmax(nv)), 7):
+        Q = P[ri[c]:ri[c + 1] - 1]
+        ctr = (lo[c] + hi[c]) / 2
+        ang = np.unwrap(np.arctan2(Q[:, 1] - ctr[1], Q[:, 0] - ctr[0]))
+        assert np.all(np.diff(ang) > 0) or np.all(np.diff(ang) < 0)
+
+
+def test_two_ring_maps_intersect(oracle):
+    from rayjoin_amd import maps, synth
+    ctx = maps.Context([synth.ring_map(800, 9000, 1), synth.ring_map(700, 9000, 2)]).load()
+    m0 = oracle.Map(ctx.maps[0].pts, ctx.maps[0].row_index, ctx.maps[0].left, ctx.maps[0].right)
+    m1 = oracle.Map(ctx.maps[1].pts, ctx.maps[1].row_index, ctx.maps[1].left, ctx.maps[1].right)
+    a, b = oracle.lsi_brute(m0, m1), oracle.lsi_grid(m0, m1, 64)["eid"]
+    assert len(a) > 20 and np.array_equal(a, b)
+    inside = oracle.pip_grid(m0, 0, ctx.maps[1].pts, 64)
+    assert 0 < (inside != 0xFFFFFFFF).sum() < len(inside)
