@@ -188,6 +188,9 @@ struct rj_handle_s {
   GridState grid[2];
   int query_order = 1;  // 0 never, 1 auto (estimate coherence), 2 always
   bool last_ordered = false;
+  // the permutation of the query being issued was sorted IN THIS CALL (main stream, shared sort scratch): such a query
+  // runs alone; a permutation that comes from a cache (a private buffer, complete long ago) pairs like no permutation
+  bool order_fresh = false;
   // coherence decisions for map-owned query sets (immutable after upload): [kind 0=segs,1=points][map]
   struct CohCache { bool valid = false; uint64_t begin = 0, n = 0; bool incoherent = false; } coh[2][2];
   // ... and the Morton permutation of such a set, kept until the map is uploaded again: repeated
@@ -1100,6 +1103,7 @@ static int order_caller_points(rj_handle h, const int64_t* pts, uint64_t n, cons
       e->perm_cap = n;
     }
     if (int r = sort_query_points(h, pts, n)) return r;
+    h->order_fresh = true;
     RJ_HIP(h, hipMemcpyAsync(e->perm, h->ord_vout, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, h->stream));
     e->has_perm = true;
     e->fresh_perm = true;   // the next estimate says what "sorted" looks like for these contents
@@ -1122,6 +1126,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
                                uint64_t key_begin) {
   *order_out = nullptr;
   h->last_ordered = false;
+  h->order_fresh = false;
   h->cur_caller = -1;
   h->cur_order = nullptr;
   if (h->query_order == 0 || n <= 64) return RJ_OK;
@@ -1150,6 +1155,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
     return RJ_OK;
   }
   if (int r = ensure_sort_scratch(h, n)) return r;
+  h->order_fresh = true;
   tic(h, RJ_T_ORDER);
   RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin));
   size_t tb = h->ord_temp_bytes;
@@ -1211,7 +1217,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   // queries (shared scratch), and not for the synchronous rj_lsi_query (nothing can run beside it).
   // "pip_concurrent" 2 decides per workload (co_pick above).
   int max_blocks = h->max_blocks;
-  const bool pairable = async_call && h->pip_concurrent != 0 && !order && !h->stats_on && qe > qb;
+  const bool pairable = async_call && h->pip_concurrent != 0 && !(order && h->order_fresh) && !h->stats_on && qe > qb;
   if (h->capturing) {
     if (order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
     h->co_mode = pairable ? (h->pip_concurrent == 2 ? (h->co_choice >= 0 ? h->co_choice : 0) : 1) : 0;
@@ -1408,7 +1414,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
   // ("auto", taking turns: still the second stream, behind everything the main stream holds so far -- whatever a
   //  stream costs the first time it is used then lands in the first, cold pair and not in another schedule's trial)
-  const bool aux = !order && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight)) &&
+  const bool aux = !(order && h->order_fresh) && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight)) &&
                    !(h->capturing && !h->cap_aux);  // (a captured step that takes turns is one stream's graph)
   if (aux && !h->capturing && h->pip_concurrent == 2 && h->co_mode == 0) {
     RJ_HIP(h, hipEventRecord(h->ev_order, h->stream));
@@ -1417,7 +1423,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   if (h->capturing && order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
   const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
-  h->co_measure = !h->capturing && h->pip_concurrent == 2 && h->lsi_inflight && !order && !h->stats_on && n > 0;
+  h->co_measure = !h->capturing && h->pip_concurrent == 2 && h->lsi_inflight && !(order && h->order_fresh) && !h->stats_on && n > 0;
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
   // in flight together (calls on ONE stream are ordered by the stream)

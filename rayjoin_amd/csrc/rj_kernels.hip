@@ -139,52 +139,61 @@ __global__ __launch_bounds__(256) void k_run_keys(const Seg* __restrict__ seg, c
 // chunk starts a new leaf: one part-filled leaf per 256 runs is the price of not being sequential): pass 1 counts
 // the leaves of every chunk, a scan places the chunks, pass 2 writes where every leaf starts.
 constexpr uint32_t kPackChunk = 256;
+// (one WAVE per chunk: the lanes fetch 64 runs' lengths and boxes at once, the greedy decision then walks them in
+//  registers -- a thread per chunk chased two dependent loads per run through memory, 0.3 ms for a 111 k-run map)
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_pack_runs(const uint32_t* __restrict__ order, const uint32_t* __restrict__ run_len,
                                                    const QBox* __restrict__ run_box, uint64_t nruns,
                                                    uint32_t solo_above, uint32_t spread, uint32_t* __restrict__ chunk_leaves,
                                                    const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ leaf_first) {
+  const int lane = lane_id();
   const uint64_t nchunks = (nruns + kPackChunk - 1) / kPackChunk;
-  for (uint64_t c = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; c < nchunks; c += (uint64_t) gridDim.x * blockDim.x) {
+  const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
+  for (uint64_t c = wave; c < nchunks; c += nwaves) {
     const uint64_t j0 = c * kPackChunk, j1 = j0 + kPackChunk < nruns ? j0 + kPackChunk : nruns;
     uint32_t cur = 0, leaves = 0;
     bool closed = false;
-    QBox u = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
+    int32_t ux0 = kEmptyMin, uy0 = kEmptyMin, ux1 = kEmptyMax, uy1 = kEmptyMax;
     uint64_t own = 0;  // sum of the half-perimeters of the runs in the leaf
     const uint32_t base = WRITE ? chunk_base[c] : 0;
-    for (uint64_t j = j0; j < j1; j++) {
-      const uint32_t r = order[j];
-      const uint32_t len = run_len[r];
-      const bool solo = len > solo_above;
-      bool join = cur != 0 && !closed && !solo && cur + len <= 64;
-      QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax}, v = u;
-      uint64_t hp = 0;
-      if (!solo) {
-        b = run_box[r];
-        hp = (uint64_t) (b.x1 - b.x0) + (uint64_t) (b.y1 - b.y0) + 2;
+    for (uint64_t jb = j0; jb < j1; jb += 64) {
+      const uint64_t j = jb + lane;
+      uint32_t len = 0;
+      QBox b = {kEmptyMin, kEmptyMin, kEmptyMax, kEmptyMax};
+      if (j < j1) {
+        const uint32_t r = order[j];
+        len = run_len[r];
+        if (len <= solo_above) b = run_box[r];
       }
-      if (join) {
+      const int n = (int) (j1 - jb < 64 ? j1 - jb : 64);
+      uint64_t starts = 0;
+      for (int k = 0; k < n; k++) {
+        const uint32_t lk = (uint32_t) bcast((int32_t) len, k);
+        const bool solo = lk > solo_above;
+        const int32_t bx0 = bcast(b.x0, k), by0 = bcast(b.y0, k), bx1 = bcast(b.x1, k), by1 = bcast(b.y1, k);
+        const uint64_t hp = solo ? 0 : (uint64_t) (bx1 - bx0) + (uint64_t) (by1 - by0) + 2;
+        bool join = cur != 0 && !closed && !solo && cur + lk <= 64;
+        const int32_t vx0 = ux0 < bx0 ? ux0 : bx0, vy0 = uy0 < by0 ? uy0 : by0, vx1 = ux1 > bx1 ? ux1 : bx1, vy1 = uy1 > by1 ? uy1 : by1;
         // ... and only while the leaf stays about as large as what it holds: where the sorted order jumps -- the curve
         // leaving one cluster of rings for the next -- a shared leaf would be a box across the gap that every ray
         // through the gap has to open (measured on the lake-shaped stand-in: 650 leaf visits per 64 points)
-        v.x0 = min(u.x0, b.x0); v.y0 = min(u.y0, b.y0); v.x1 = max(u.x1, b.x1); v.y1 = max(u.y1, b.y1);
-        const uint64_t uhp = (uint64_t) (v.x1 - v.x0) + (uint64_t) (v.y1 - v.y0);
-        join = uhp <= (uint64_t) spread * (own + hp);
+        if (join) join = (uint64_t) (vx1 - vx0) + (uint64_t) (vy1 - vy0) <= (uint64_t) spread * (own + hp);
+        if (join) {
+          cur += lk;
+          ux0 = vx0; uy0 = vy0; ux1 = vx1; uy1 = vy1;
+          own += hp;
+        } else {
+          starts |= 1ull << k;
+          cur = lk;
+          closed = solo;
+          ux0 = bx0; uy0 = by0; ux1 = bx1; uy1 = by1;
+          own = hp;
+        }
       }
-      if (join) {
-        cur += len;
-        u = v;
-        own += hp;
-      } else {
-        if (WRITE) leaf_first[base + leaves] = (uint32_t) j;
-        leaves++;
-        cur = len;
-        closed = solo;
-        u = b;
-        own = hp;
-      }
+      if (WRITE && ((starts >> lane) & 1)) leaf_first[base + leaves + (uint32_t) rank_below(starts)] = (uint32_t) j;
+      leaves += (uint32_t) __popcll(starts);
     }
-    if (!WRITE) chunk_leaves[c] = leaves;
+    if (!WRITE && lane == 0) chunk_leaves[c] = leaves;
   }
 }
 // exclusive scan of n counts by ONE block (n = runs / 256: tens of thousands at most), the total behind the last entry
@@ -1828,8 +1837,10 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 __host__ __device__ __forceinline__ int walk2_list(int top) { return top <= 3 ? kWalkList : 4; }
 __host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) walk2_list(top) * 256 * 2; }
 
+// (96 SGPRs: above that the hardware admits one block per CU fewer than the occupancy query reports, and the shared
+//  schedule's 5 walk + 2 k_lsi2 blocks per CU no longer fit -- the skyline pointer took it to 100: 0.785 -> 0.852 ms)
 template <int LIST>
-__global__ __launch_bounds__(256, 6) void k_pip_walk2(PipArgs A) {
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk2(PipArgs A) {
   extern __shared__ uint4 walk_smem[];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
@@ -2227,7 +2238,7 @@ hipError_t launch_pack_runs(hipStream_t st, const uint32_t* order, const uint32_
                             unsigned long long* total_out) {
   if (nruns == 0) return hipSuccess;
   const uint64_t nchunks = pack_runs_chunks(nruns);
-  const int grid = grid_for(nchunks, 256, 4096);
+  const int grid = grid_for(nchunks, 4, 8192);  // (a wave per chunk)
   hipLaunchKernelGGL(k_pack_runs<false>, dim3(grid), dim3(256), 0, st, order, run_len, run_box, nruns, solo_above, spread, chunk_leaves,
                      (const uint32_t*) nullptr, (uint32_t*) nullptr);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, chunk_leaves, chunk_base, nchunks, total_out);
