@@ -37,7 +37,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-SECONDARY = (("USCounty", "NestedBlockGroup"), ("WaterBodies", "BlockGroup"))
+# the harder pairs that ride in the default line: nested maps (shared vertices), the 4-level WaterBodies lattice, and a
+# LAKE-SHAPED base map (2.44 M isolated rings of ~10 edges: the topology the reference's water-body / lake / park
+# inputs have and no lattice has -- short rings sharing leaves, a third of the query vertices with nothing above them)
+SECONDARY = (("USCounty", "NestedBlockGroup"), ("WaterBodies", "BlockGroup"), ("WaterBodiesLike", "BlockGroup"))
 
 
 def parse():

@@ -277,81 +277,77 @@ typedef enum {
 } rj_timer;
 /* HIP-event time (ms) of the last launch of that stage on the handle's stream; syncs. */
 int rj_last_ms(rj_handle h, int which, float* ms);
+/* every stage at once: ms[i] = rj_last_ms(h, i) for i < n (at most the number of stages), -1 for a stage that has
+ * not run -- one call instead of one per stage between two steps of a timed loop */
+int rj_last_ms_all(rj_handle h, float* ms, int n);
 /* traversal statistics of the last LSI/PIP query (diagnostic; mirrors the reference's
  * "Total tests"/"Visited nodes" debug counters, src/app/lsi_lbvh.h:37-42,93-94):
  * stats[0] = leaf blocks visited, [1] = candidate pairs tested exactly, [2] = nodes expanded,
  * [3] = box tests in the leaf loop; [4..9] = summed per-wave cycle stamps of the instrumented
  * build (total, node expansion, leaf loop, dense predicate phase, merge rounds, max wave total).
  * Collected only after rj_set_option(h,"stats",1), which selects a separate, slower kernel. */
-/* ---- a step as one submission ------------------------------------------------------------ */
-/* The asynchronous queries issued between rj_graph_begin and rj_graph_end (rj_lsi_query_async, rj_lsi_points_async,
- * rj_pip_query_async, rj_lsi_count_to -- on both of the handle's streams) are captured into one hipGraph instead of
- * being run (one graph per stream: the two sides of a step that share the chip must stay on two streams); rj_graph_launch
- * replays them: two submissions per step of a join instead of seven launches and eight event records (the reference: run_query.cu:297-303 issues its kernels one by one).  The step must
- * have run once normally (buffers allocated, coherence estimated, "pip_schedule" settled); arguments, grids and
- * the schedule are frozen as they were at capture; a captured LSI query's count is copied to the host at the end of
- * the graph and read with rj_graph_lsi_count (which waits for the stream; RJ_E_OVERFLOW like rj_lsi_query_finish).
- * rj_last_ms works on a replayed step.  Uploading a map or building an index invalidates nothing by itself: capture
- * again after it.  Not with the instrumented kernels or re-ordered query sets. */
-int rj_graph_begin(rj_handle h, int id); /* id 0..3: a handle keeps up to four captured steps (e.g. one per result buffer) */
-int rj_graph_end(rj_handle h);
-int rj_graph_launch(rj_handle h, int id);
-int rj_graph_lsi_count(rj_handle h, uint64_t capacity, uint64_t* n_found);
-/* every stage at once: ms[i] = rj_last_ms(h, i) for i < n (at most the number of stages), -1 for a stage that has
- * not run -- one call instead of one per stage between two steps of a timed loop */
-int rj_last_ms_all(rj_handle h, float* ms, int n);
 int rj_last_stats(rj_handle h, uint64_t stats[16]);
-/* options: "stats" 0/1 (instrumented kernels); "chunk_groups" n (consecutive groups handed to a
- * wave at a time; 0 = automatic, the default: 8 for LSI, 6 for PIP); "group_lanes" 0/4/8/16/32/64 (queries per wave; 0 = automatic: 64
- * unless the query set is too small to fill the chip); "max_blocks" n; "own_stream" 1;
- * "leaf_order" 1 (default; environment RJ_LEAF_ORDER=0 changes it) / 0: what the NEXT rj_build_lbvh makes a leaf of --
- * 1: a run of <= 64 consecutive edges of one POLYLINE, the analogue of the reference's RT grouping
- * (src/rt/primitive.h:120-260): chains are stitched through their shared end points by straightest continuation, the
- * polylines cut into near-equal runs (<= 32 edges where the map's chains average fewer than 16), once per uploaded map on
- * the host, the first time such an index is built -- unless the leaves would be less than 40 % full (isolated polygons of a
- * few edges); 0: 64 neighbours along the Hilbert curve.  Results never depend on it.  rj_get_option "leaf_order_used0/1"
- * says what the index of map 0 / 1 was built with, "leaf_slots0/1" its size in slots (64 per leaf);
- * "pip_walk" 1 auto (default: a PIP query runs k_pip_walk, the integer-only traversal, then k_pip_exact over the
- * candidate lists it left and k_pip over the few points whose list overflowed -- unless the last query of this size
- * left more than 30 % of its points to k_pip) / 0 k_pip alone / 2 always the three passes;
- * "lsi_segments" 2 (default) / 1: query segments per lane of the LSI kernel.  2: k_lsi2 takes 128 consecutive query
- * segments per wave through one traversal where the query set is large (at least two full 64-segment groups per resident
- * wave) and no visit counters are being collected; k_lsi otherwise, and always with 1.  Same pairs either way;
- * rj_get_option "lsi_last_segments" says what the last LSI query ran;
- * "pip_walk_points" 2 (default) / 1: query points per lane of the PIP walk.  2: k_pip_walk2 takes 128 consecutive query
- * positions per wave through one traversal (node expansions, pops and the leaf blocks' loads shared by two point sets)
- * where the query set fills 64-position groups, the base tree has at most 3 levels above its leaf blocks and no visit
- * counters are being collected; k_pip_walk (one point per lane) otherwise, and always with 1.  Same results either way;
- * rj_get_option "pip_last_walk_points" says what the last PIP query ran;
- * "timers" 1 (default) / 0: whether the stage timers behind rj_last_ms / rj_last_ms_all are recorded (two event records
- * per stage; a step of a join has four stages: ~1 % of a 0.9 ms step).  With 0, rj_last_ms keeps returning the values of
- * the last recorded query; while "pip_concurrent" 2 is still trying schedules the timers are recorded regardless;
- * "lsi_points_split" -1 (default) / 0 / 1: how rj_lsi_points* produce the records -- 1: k_lsi_points decides each stored
- * coordinate from one exact floor division (no gcd: 98-99 % of the pairs of map-like data) and k_lsi_points_gcd simplifies
- * the rational (rational.h:198-203) only for the pairs that declines; 0: k_lsi_points_gcd for every pair, one latency
- * chain instead of two; -1: two kernels from 384 Ki pairs on, going by the count of the last query when the count is on
- * the device.  The records never depend on it.  rj_get_option "lsi_points_last_split" / "lsi_points_gcd_pairs" report
- * the form of the last launch and how many pairs its gcd leg took;
- * "query_order" 0 never / 1 auto (default: re-order a query set along the Morton curve when
- * consecutive queries are spatially scattered, e.g. the generated workloads of
- * src/run_query.cu:102-167) / 2 always.   "pip_concurrent" 0 never (default) / 1 always /
- * 2 auto: the caller issues rj_lsi_query_async and rj_pip_query_async in PAIRS (the step of a join:
- * both only read the maps and the index) and the two kernels may run beside each other instead of
- * taking turns: the LSI kernel runs on a reduced grid (1-4 blocks per compute unit, about 2: what fits a unit's
- * registers beside 6 blocks of the PIP walk, see rj_api.hip co_ratio) and the
- * PIP kernels, on a second stream owned by the handle, fill the rest.  That is faster on some workloads and slower on others,
- * so "auto" measures the first four pairs (taking turns / sharing the chip as above / sharing it with the neighbouring
- * split on the side that one's imbalance points to / beside each other on full grids), keeps the fastest from the fifth pair on -- the reference's
- * five warm-up queries settle it -- and decides again when the index, a map or the query size changes.  (With 1, an asynchronous LSI query issued alone is slow; the synchronous
- * rj_lsi_query and a PIP query without an LSI query in flight always use the whole chip.)  The PIP
- * query's inputs must be complete when the call
- * is made; its outputs are complete after rj_sync, rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL). */
+
+/* ---- options ---------------------------------------------------------------------------
+ * rj_set_option(h, name, value).  NO option changes a result: they choose kernels, leaves and schedules.
+ *
+ * name               values (default first)   what it does
+ * ------------------ ------------------------ ------------------------------------------------------------------------
+ * "leaf_order"       1 / 0                    what the NEXT rj_build_lbvh makes a leaf of.  1: polyline runs -- chains
+ *                                             stitched through their shared end points by straightest continuation and
+ *                                             cut into near-equal runs of <= 64 edges ON THE DEVICE by the first build of
+ *                                             an uploaded map (the analogue of the reference's RT grouping,
+ *                                             src/rt/primitive.h:120-260); consecutive short runs of the sorted order
+ *                                             share a leaf (maps of isolated rings).  0: 64 neighbours along the Hilbert
+ *                                             curve.  (Environment RJ_LEAF_ORDER=0 changes the default.)
+ * "skyline"          -1 / 0 / 1               the per-x-bucket top of the map that proves a PIP miss without a traversal:
+ *                                             -1 built where most chains are closed rings, 0 never, 1 always.
+ * "pip_walk"         1 / 0 / 2                a PIP query = k_pip_walk* (integer-only traversal) + k_pip_exact (exact
+ *                                             predicate over the candidate lists; its first blocks locate the points
+ *                                             whose list overflowed).  1: unless the last query of this size left > 30 %
+ *                                             of its points over; 0: k_pip alone; 2: always the passes.
+ * "pip_walk_points"  2 / 1                    query points per lane of the walk (k_pip_walk2 / k_pip_walk); 2 applies to
+ *                                             query sets that fill 64-position groups.
+ * "lsi_segments"     2 / 1                    query segments per lane of the LSI kernel (k_lsi2 / k_lsi); 2 applies to
+ *                                             query sets of at least two full groups per resident wave.
+ * "lsi_points_split" -1 / 0 / 1               how rj_lsi_points* make the 48-byte records: 1 a gcd-free kernel + the gcd
+ *                                             kernel over the pairs it declines, 0 the gcd kernel for every pair, -1 two
+ *                                             kernels from 384 Ki pairs on.
+ * "query_order"      1 / 0 / 2                re-order a query set along the Morton curve: 1 when consecutive queries are
+ *                                             spatially scattered (e.g. the generated workloads of
+ *                                             src/run_query.cu:102-167), 0 never, 2 always.
+ * "pip_concurrent"   0 / 1 / 2                the caller issues rj_lsi_query_async and rj_pip_query_async in PAIRS (the
+ *                                             step of a join: both only read the maps and the index).  1: the two sides
+ *                                             share the chip (the LSI kernel on a reduced grid, the PIP kernels on the
+ *                                             handle's second stream fill the rest); 2: the handle measures the first
+ *                                             four pairs -- taking turns / sharing / sharing with the neighbouring split
+ *                                             / beside each other on full grids -- and keeps the fastest from the fifth
+ *                                             on (the reference's five warm-up queries settle it), deciding again when
+ *                                             the index, a map or the query size changes; 0: every kernel on the whole
+ *                                             chip (a caller that issues one kind of query).  The PIP query's inputs must
+ *                                             be complete when the call is made; its outputs are complete after rj_sync,
+ *                                             rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL).
+ * "timers"           1 / 0                    record the stage timers behind rj_last_ms (two event records per stage,
+ *                                             ~1 % of a 0.9 ms step); while "pip_concurrent" 2 is still trying schedules
+ *                                             they are recorded regardless.
+ * "stats"            0 / 1                    the instrumented kernels (visit counters for rj_last_stats; slower).
+ * "own_stream"       1                        back to the handle's private stream (see rj_set_stream).
+ *
+ * rj_get_option reads any of these, and what the handle did or decided:
+ *   "leaf_order_used0/1", "leaf_slots0/1", "leaf_runs0/1", "skyline_used0/1", "closed_chains0/1"   the index of map 0 / 1
+ *   "stitch_rounds", "stitch_loop_ends"                         the last run cutting (pointer-jumping rounds; closed loops)
+ *   "pip_schedule" (0 turns, 1 shared, 2 full grids, -1 still trying), "pip_schedule_trials", "pip_schedule_us0/1/2",
+ *   "lsi_share_blocks", "pip_share_blocks"                      what "pip_concurrent" 2 measured and settled on
+ *   "lsi_last_segments", "pip_last_walk_points", "pip_last_passes", "lsi_points_last_split", "lsi_points_gcd_pairs",
+ *   "pip_rest", "pip_rest_aux", "query_last_ordered"            what the last query ran */
 int rj_set_option(rj_handle h, const char* name, int64_t value);
-/* current value of an option of rj_set_option; additionally "pip_schedule": what "pip_concurrent" 2 has
- * decided for the current workload (0 taking turns, 1 sharing the chip, 2 beside each other on full grids,
- * -1 still trying), "pip_schedule_trials": the pairs it has measured so far, "lsi_share_blocks" /
- * "pip_share_blocks": the grids of schedule 1. */
 int rj_get_option(rj_handle h, const char* name, int64_t* value);
+/* Experiment knobs for tools/ and the fault-path tests -- grids, chunk sizes, run lengths ("chunk_groups",
+ * "group_lanes", "max_blocks", "lsi_share_blocks", "pip_share_blocks", "stack_cap", "run_cap", "pack_solo",
+ * "pack_spread"; rj_api.hip lists their ranges).  Not needed by a host of the library, never a correctness input,
+ * no promise that a name survives a round. */
+int rj_set_debug_option(rj_handle h, const char* name, int64_t value);
+int rj_get_debug_option(rj_handle h, const char* name, int64_t* value);
 
 /* ---- device memory helpers (for hosts without their own allocator) -------------------- */
 int rj_dev_alloc(rj_handle h, size_t bytes, void** out_dev);

@@ -60,10 +60,6 @@ SYMBOLS = {
     "rj_exchange_u32_finish": (_int, [_vp]),
     "rj_exchange_verdict": (_int, [_vp, _vp, _int, C.POINTER(_u64), C.POINTER(_int)]),
     "rj_last_ms_all": (_int, [_vp, _vp, _int]),
-    "rj_graph_begin": (_int, [_vp, _int]),
-    "rj_graph_end": (_int, [_vp]),
-    "rj_graph_launch": (_int, [_vp, _int]),
-    "rj_graph_lsi_count": (_int, [_vp, _u64, C.POINTER(_u64)]),
     "rj_overlay_edge_xsects": (_int, [_vp, _int, _vp, _u64, _vp]),
     "rj_pip_query": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
     "rj_pip_query_async": (_int, [_vp, _int, _int, _vp, _u64, _u64, _vp, _vp]),
@@ -73,6 +69,8 @@ SYMBOLS = {
     "rj_last_ms": (_int, [_vp, _int, C.POINTER(C.c_float)]),
     "rj_last_stats": (_int, [_vp, C.POINTER(_u64)]),
     "rj_set_option": (_int, [_vp, C.c_char_p, _i64]),
+    "rj_set_debug_option": (_int, [_vp, C.c_char_p, _i64]),
+    "rj_get_debug_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "rj_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "rj_dev_alloc": (_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rj_dev_free": (_int, [_vp, _vp]),
@@ -247,6 +245,15 @@ class Handle:
         self._check(self.L.rj_get_option(self.h, name.encode(), C.byref(v)))
         return int(v.value)
 
+    def set_debug_option(self, name, value):
+        """experiment knobs (grids, chunk sizes, run lengths: rj_set_debug_option)"""
+        self._check(self.L.rj_set_debug_option(self.h, name.encode(), int(value)))
+
+    def get_debug_option(self, name):
+        v = _i64()
+        self._check(self.L.rj_get_debug_option(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
@@ -414,23 +421,6 @@ class Handle:
         ms = C.c_float()
         self._check(self.L.rj_last_ms(self.h, which, C.byref(ms)))
         return ms.value
-
-    def graph_begin(self, gid=0):
-        self._check(self.L.rj_graph_begin(self.h, gid))
-
-    def graph_end(self):
-        self._check(self.L.rj_graph_end(self.h))
-
-    def graph_launch(self, gid=0):
-        self._check(self.L.rj_graph_launch(self.h, gid))
-
-    def graph_lsi_count(self, capacity):
-        n = _u64()
-        rc = self.L.rj_graph_lsi_count(self.h, capacity, C.byref(n))
-        if rc == RJ_E_OVERFLOW:
-            raise QueueOverflow(self.L.rj_last_error_string(self.h).decode(), n.value)
-        self._check(rc)
-        return n.value
 
     def last_ms_all(self):
         """-> list of the last duration of every stage (RJ_T_* order), -1 where a stage has not run"""

@@ -128,19 +128,6 @@ struct rj_handle_s {
   int pip_share_blocks() const { return pip_share_set ? pip_share_set : cus * 5; }  // (k_pip without the walk; the walk gets its full grid less one block per CU)
   bool aux_pending = false;          // something was enqueued on aux_stream since it was last joined
   hipEvent_t ev_order = nullptr;     // "taking turns" under "pip_concurrent" 2: the PIP kernels still use aux_stream, behind this event
-  // rj_graph_begin .. rj_graph_end: the async queries issued in between are captured into ONE hipGraph (both streams),
-  // replayed by rj_graph_launch -- a step of a join as one submission instead of seven launches and eight event records
-  bool capturing = false;
-  bool cap_aux = false;              // the second stream is captured too, into a graph of its own
-  bool cap_lsi = false;              // an LSI query is part of it: its count is copied to the host at the end
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  static constexpr int kGraphs = 4;   // captured steps per handle (e.g. one per result buffer of a double-buffered caller)
-  int cap_id = 0;                    // the slot being captured
-  // which counter kinds the captured step uses (bit 0 LSI, 1 / 2 PIP on main / aux, 3 / 4 the walk on main / aux, 5 the
-  // records' list): a replay runs on set 0 of those and leaves set 1 cleared, so the next plain launch must take set 1
-  int cap_kinds = 0, graph_kinds[kGraphs] = {0};
-  hipGraph_t graph[kGraphs] = {nullptr}, graph_aux[kGraphs] = {nullptr};  // one graph per stream: ROCm runs the branches of ONE
-  hipGraphExec_t graph_exec[kGraphs] = {nullptr}, graph_exec_aux[kGraphs] = {nullptr};  // graph one after the other (measured)
   hipStream_t stream = nullptr;
   MapState map[2];
   BvhState bvh[2];
@@ -486,9 +473,7 @@ int rj_create(int device_id, rj_handle* out) {
     ok = hipEventCreate(&h->ev[t][0]) == hipSuccess && hipEventCreate(&h->ev[t][1]) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&h->ev_count[0], hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_count[1], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
   // load every code object of the library now (a kernel's first launch loads its file's code object: milliseconds
   // that would otherwise land in the first upload, the first index build and the first query)
   ok = ok && warm_query_kernels(h->stream) == hipSuccess && warm_grid_kernels(h->stream) == hipSuccess &&
@@ -514,14 +499,6 @@ int rj_destroy(rj_handle h) {
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
   for (int k = 0; k < 2; k++) if (h->ev_count[k]) (void) hipEventDestroy(h->ev_count[k]);
   if (h->ev_order) (void) hipEventDestroy(h->ev_order);
-  if (h->ev_fork) (void) hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void) hipEventDestroy(h->ev_join);
-  for (int g = 0; g < rj_handle_s::kGraphs; g++) {
-    if (h->graph_exec[g]) (void) hipGraphExecDestroy(h->graph_exec[g]);
-    if (h->graph[g]) (void) hipGraphDestroy(h->graph[g]);
-    if (h->graph_exec_aux[g]) (void) hipGraphExecDestroy(h->graph_exec_aux[g]);
-    if (h->graph_aux[g]) (void) hipGraphDestroy(h->graph_aux[g]);
-  }
   (void) hipFree(h->arena);
   if (h->comm) (void) rj_comm_destroy(h);
   (void) hipStreamDestroy(h->own_stream);
@@ -550,7 +527,6 @@ int rj_set_stream(rj_handle h, void* s) {
 
 int rj_sync(rj_handle h) {
   RJ_CHECK_H(h);
-  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_sync: a step is being captured (rj_graph_end first)");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   h->lsi_shared = h->lsi_inflight = false;
@@ -562,7 +538,6 @@ const char* rj_last_error_string(rj_handle h) { return h ? h->err.c_str() : "nul
 
 int rj_invalidate(rj_handle h) {
   RJ_CHECK_H(h);
-  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_invalidate: a step is being captured");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipStreamSynchronize(h->stream));  // (estimates in flight write the sets' words)
   RJ_HIP(h, join_aux(h));
@@ -577,9 +552,6 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   RJ_CHECK_H(h);
   if (!name || !value) return fail(h, RJ_E_INVALID, "rj_get_option: null argument");
   if (!strcmp(name, "stats")) *value = h->stats_on;
-  else if (!strcmp(name, "chunk_groups")) *value = h->chunk_groups;
-  else if (!strcmp(name, "group_lanes")) *value = h->group_lanes;
-  else if (!strcmp(name, "max_blocks")) *value = h->max_blocks;
   else if (!strcmp(name, "query_order")) *value = h->query_order;
   else if (!strcmp(name, "query_last_ordered")) *value = h->last_ordered ? 1 : 0;  // the last query ran through a Morton permutation of its queries
   else if (!strcmp(name, "pip_concurrent")) *value = h->pip_concurrent;
@@ -609,12 +581,9 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "leaf_runs0") || !strcmp(name, "leaf_runs1")) *value = h->map[name[9] - '0'].runs_cut ? (int64_t) h->map[name[9] - '0'].nruns : -1;  // polyline runs cut for map 0 / 1 (-1: none cut)
   else if (!strcmp(name, "stitch_rounds")) *value = h->stitch_stats[0];      // the last run cutting: pointer-jumping rounds that had work
   else if (!strcmp(name, "stitch_loop_ends")) *value = h->stitch_stats[1];   // ... chain ends on closed loops of paired chains
-  else if (!strcmp(name, "debug_run_cap")) *value = h->debug_run_cap;
   else if (!strcmp(name, "skyline")) *value = h->skyline;
   else if (!strcmp(name, "skyline_used0") || !strcmp(name, "skyline_used1")) *value = h->bvh[name[12] - '0'].use_sky ? 1 : 0;
   else if (!strcmp(name, "closed_chains0") || !strcmp(name, "closed_chains1")) *value = (int64_t) h->map[name[13] - '0'].closed_chains;
-  else if (!strcmp(name, "debug_pack_solo")) *value = h->debug_pack_solo;
-  else if (!strcmp(name, "debug_pack_spread")) *value = h->debug_pack_spread;
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
   else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
@@ -638,21 +607,6 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "leaf_order")) {
     if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_order: 0 Hilbert neighbours, 1 chain runs");
     h->leaf_order = (int) value;
-    return RJ_OK;
-  }
-  if (!strcmp(name, "debug_pack_solo")) {  // (experiments: runs longer than this keep a leaf to themselves; 0 = the default)
-    if (value < 0 || value > 64) return fail(h, RJ_E_INVALID, "debug_pack_solo: 0..64");
-    h->debug_pack_solo = (int) value;
-    return RJ_OK;
-  }
-  if (!strcmp(name, "debug_pack_spread")) {  // (experiments: a shared leaf may be this many times as large as its runs; 0 = the default)
-    if (value < 0 || value > 1000000) return fail(h, RJ_E_INVALID, "debug_pack_spread out of range");
-    h->debug_pack_spread = (int) value;
-    return RJ_OK;
-  }
-  if (!strcmp(name, "debug_run_cap")) {  // (experiments: edges per polyline run of the NEXT first build of a map; 0 = by the mean chain length)
-    if (value != 0 && (value < 2 || value > 64)) return fail(h, RJ_E_INVALID, "debug_run_cap: 0 or 2..64");
-    h->debug_run_cap = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "skyline")) {
@@ -685,38 +639,59 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     h->pip_walk = (int) value;
     return RJ_OK;
   }
-  if (!strcmp(name, "lsi_share_set") || !strcmp(name, "pip_share_set")) {  // (tuning / tools: the grids of schedule 1)
-    if (value < 0 || value > (1 << 20)) return fail(h, RJ_E_INVALID, "%s out of range", name);
-    (name[0] == 'l' ? h->lsi_share_set : h->pip_share_set) = (int) value;
-    return RJ_OK;
-  }
   if (!strcmp(name, "query_order")) {
     if (value < 0 || value > 2) return fail(h, RJ_E_INVALID, "query_order: 0 never, 1 auto, 2 always");
     h->query_order = (int) value;
     return RJ_OK;
   }
-  if (!strcmp(name, "group_lanes")) {
+  return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
+}
+
+// Experiment knobs (tools/, tests of the fault path): not part of what a host of the library needs, never a
+// correctness input, no promise that they survive a round.
+int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
+  RJ_CHECK_H(h);
+  if (!name) return fail(h, RJ_E_INVALID, "null option name");
+  struct { const char* name; int* var; int64_t lo, hi; } knobs[] = {
+      {"chunk_groups", &h->chunk_groups, 0, 4096},        // consecutive groups handed to a wave at a time (0: per kernel, 8 / 6)
+      {"max_blocks", &h->max_blocks, 1, 1 << 20},         // cap on the persistent grids
+      {"lsi_share_blocks", &h->lsi_share_set, 0, 1 << 20},  // fixed grids of the shared schedule (0: derived)
+      {"pip_share_blocks", &h->pip_share_set, 0, 1 << 20},
+      {"stack_cap", &h->debug_stack_cap, 1, 1 << 30},     // instrumented kernels: fewer traversal-stack entries (fault path)
+      {"run_cap", &h->debug_run_cap, 0, 64},              // edges per polyline run of the next first build of a map (0: 64)
+      {"pack_solo", &h->debug_pack_solo, 0, 64},          // a run longer than this never shares its leaf (0: 48)
+      {"pack_spread", &h->debug_pack_spread, 0, 1000000}, // a shared leaf may be this many times as large as its runs (0: 8)
+  };
+  for (auto& k : knobs)
+    if (!strcmp(name, k.name)) {
+      if (value < k.lo || value > k.hi) return fail(h, RJ_E_INVALID, "%s: %lld..%lld", name, (long long) k.lo, (long long) k.hi);
+      if (!strcmp(name, "run_cap") && value == 1) return fail(h, RJ_E_INVALID, "run_cap: 0 or 2..64");
+      *k.var = (int) value;
+      return RJ_OK;
+    }
+  if (!strcmp(name, "group_lanes")) {  // queries per wave (0: 64 unless the query set is small)
     if (value != 0 && value != 4 && value != 8 && value != 16 && value != 32 && value != 64)
       return fail(h, RJ_E_INVALID, "group_lanes: 0 (auto), 4, 8, 16, 32 or 64");
     h->group_lanes = (int) value;
     return RJ_OK;
   }
-  if (!strcmp(name, "chunk_groups")) {
-    if (value < 0 || value > 4096) return fail(h, RJ_E_INVALID, "chunk_groups out of range (0 = automatic)");
-    h->chunk_groups = (int) value;
-    return RJ_OK;
-  }
-  if (!strcmp(name, "debug_stack_cap")) {  // tests only (honoured by the "stats" kernels): shrink the traversal stacks to exercise the fault path
-    if (value < 1) return fail(h, RJ_E_INVALID, "debug_stack_cap must be positive");
-    h->debug_stack_cap = value > (1 << 30) ? (1 << 30) : (int) value;
-    return RJ_OK;
-  }
-  if (!strcmp(name, "max_blocks")) {
-    if (value < 1 || value > (1 << 20)) return fail(h, RJ_E_INVALID, "max_blocks out of range");
-    h->max_blocks = (int) value;
-    return RJ_OK;
-  }
-  return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
+  return fail(h, RJ_E_INVALID, "unknown debug option '%s'", name);
+}
+
+int rj_get_debug_option(rj_handle h, const char* name, int64_t* value) {
+  RJ_CHECK_H(h);
+  if (!name || !value) return fail(h, RJ_E_INVALID, "rj_get_debug_option: null argument");
+  if (!strcmp(name, "chunk_groups")) *value = h->chunk_groups;
+  else if (!strcmp(name, "group_lanes")) *value = h->group_lanes;
+  else if (!strcmp(name, "max_blocks")) *value = h->max_blocks;
+  else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_set;
+  else if (!strcmp(name, "pip_share_blocks")) *value = h->pip_share_set;
+  else if (!strcmp(name, "stack_cap")) *value = h->debug_stack_cap;
+  else if (!strcmp(name, "run_cap")) *value = h->debug_run_cap;
+  else if (!strcmp(name, "pack_solo")) *value = h->debug_pack_solo;
+  else if (!strcmp(name, "pack_spread")) *value = h->debug_pack_spread;
+  else return fail(h, RJ_E_INVALID, "unknown debug option '%s'", name);
+  return RJ_OK;
 }
 
 int rj_upload_map(rj_handle h, int map_id, const int64_t* xy, uint64_t np, const uint32_t* row_index,
@@ -1059,7 +1034,6 @@ static int order_caller_points(rj_handle h, const int64_t* pts, uint64_t n, cons
   bool incoherent = false;
   if (!e) {
     // first sight of this array: one estimate with a host round trip (a captured step cannot hold one)
-    if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its coherence estimate needs a host round trip)");
     slot = 0;  // a free set, else the one used longest ago
     for (int k = 0; k < rj_handle_s::kCallerSets; k++) {
       if (!h->caller[k].valid) { slot = k; break; }
@@ -1093,7 +1067,6 @@ static int order_caller_points(rj_handle h, const int64_t* pts, uint64_t n, cons
   e->stamp = ++h->caller_clock;
   e->queries++;
   if (incoherent) {
-    if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
     if (e->perm_cap < n) {
       RJ_HIP(h, hipStreamSynchronize(h->stream));  // (the old permutation may be in use)
       RJ_HIP(h, join_aux(h));
@@ -1137,7 +1110,6 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
     if (cc && cc->valid && cc->begin == key_begin && cc->n == n) {
       incoherent = cc->incoherent;  // same immutable range as last time: no estimate, no sync
     } else {
-      if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its coherence estimate needs a host round trip)");
       RJ_HIP(h, hipMemsetAsync(h->d_counter + 4, 0, 16, h->stream));
       RJ_HIP(h, launch_group_extent(h->stream, points, pts, segs, begin, n, h->d_counter + 4));
       RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 20, h->d_counter + 4, 16, hipMemcpyDeviceToHost, h->stream));
@@ -1199,7 +1171,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   a.qbeg = qb; a.qend = qe;
   a.base_is_map0 = base_map_id == 0;
   a.out = pairs_dev; a.cap = capacity;
-  const int flip = h->capturing ? 0 : h->flip_lsi;  // (a captured step clears its own counters: rj_graph_begin)
+  const int flip = h->flip_lsi;
   a.counter = h->d_counter + flip;
   a.work_counter = (unsigned int*) (h->d_counter + kSchedLsi + flip * kSchedBlockWords);
   a.next_counter = h->d_counter + (1 - flip);
@@ -1218,14 +1190,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   // "pip_concurrent" 2 decides per workload (co_pick above).
   int max_blocks = h->max_blocks;
   const bool pairable = async_call && h->pip_concurrent != 0 && !(order && h->order_fresh) && !h->stats_on && qe > qb;
-  if (h->capturing) {
-    if (order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
-    h->co_mode = pairable ? (h->pip_concurrent == 2 ? (h->co_choice >= 0 ? h->co_choice : 0) : 1) : 0;
-    h->cap_lsi = true;
-    if (qe > qb) h->cap_kinds |= 1;
-  } else {
-    h->co_mode = pairable ? (h->pip_concurrent == 2 ? co_pick(h, qe - qb) : 1) : 0;
-  }
+  h->co_mode = pairable ? (h->pip_concurrent == 2 ? co_pick(h, qe - qb) : 1) : 0;
   h->lsi_inflight = async_call && qe > qb;
   h->co_measure = h->co_points = false;
   h->lsi_shared = pairable && h->co_mode == 1;
@@ -1234,7 +1199,7 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   tic(h, RJ_T_LSI_KERNEL);  // (after co_pick, which reads the previous pair's events)
   if (qe > qb) {
     RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks, h->lsi_segments, &h->last_lsi_segments));
-    if (!h->capturing) h->flip_lsi = 1 - flip;
+    h->flip_lsi = 1 - flip;
   } else {
     RJ_HIP(h, hipMemsetAsync(a.counter, 0, 8, h->stream));  // (an empty query: nothing ran that could have counted)
   }
@@ -1251,7 +1216,6 @@ int rj_lsi_query_async(rj_handle h, int base_map_id, int query_map_id, uint64_t 
 
 int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
   RJ_CHECK_H(h);
-  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_lsi_query_finish: a step is being captured (its count arrives with rj_graph_lsi_count)");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipMemcpyAsync(h->h_pinned, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream));
   if (h->stats_on) RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 1, h->d_stats, 128, hipMemcpyDeviceToHost, h->stream));
@@ -1271,7 +1235,6 @@ int rj_lsi_query_finish(rj_handle h, uint64_t capacity, uint64_t* n_found) {
 int rj_lsi_count_async(rj_handle h, int slot) {
   RJ_CHECK_H(h);
   if (slot < 0 || slot > 1) return fail(h, RJ_E_INVALID, "rj_lsi_count_async: slot is 0 or 1");
-  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_lsi_count_async: a step is being captured");
   if (int r = set_device(h)) return r;
   RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 28 + slot, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipEventRecord(h->ev_count[slot], h->stream));
@@ -1318,7 +1281,7 @@ constexpr uint64_t kPointsSplitAbove = 384 * 1024;
 static hipError_t lsi_points_on_stream(rj_handle h, const uint32_t* pairs_dev, uint64_t n, const unsigned long long* n_dev, XsectRec* out) {
   const uint64_t seen = n_dev ? (uint64_t) h->h_rest[2] : n;
   const bool split = n < (1ull << 32) && (h->points_split >= 0 ? h->points_split == 1 : (seen == ~0ull || seen >= kPointsSplitAbove));
-  if (split && h->slow_cap < n && !h->capturing) {  // (captured: whatever list there is, or the one-kernel form)
+  if (split && h->slow_cap < n) {
     hipError_t e = hipStreamSynchronize(h->stream);  // (the list may be in use by records still being produced)
     if (e != hipSuccess) return e;
     (void) hipFree(h->slow_list);
@@ -1331,11 +1294,10 @@ static hipError_t lsi_points_on_stream(rj_handle h, const uint32_t* pairs_dev, u
     }
   }
   uint32_t* list = split && h->slow_cap >= n ? h->slow_list : nullptr;
-  const int f = h->capturing ? 0 : h->flip_slow;
+  const int f = h->flip_slow;
   hipError_t e = launch_lsi_points(h->stream, h->map[0].seg, h->map[1].seg, pairs_dev, n, n_dev, out, list,
                                    h->d_counter + kSlowCountWord + f, h->d_counter + kSlowCountWord + (1 - f), h->d_rest + 2);
-  if (list && !h->capturing) h->flip_slow = 1 - f;
-  if (list && h->capturing) h->cap_kinds |= 32;
+  if (list) h->flip_slow = 1 - f;
   h->last_points_split = list ? 1 : 0;
   return e;
 }
@@ -1414,20 +1376,18 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // when the query went through the re-ordering pass or the instrumented build (shared scratch).
   // ("auto", taking turns: still the second stream, behind everything the main stream holds so far -- whatever a
   //  stream costs the first time it is used then lands in the first, cold pair and not in another schedule's trial)
-  const bool aux = !(order && h->order_fresh) && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight)) &&
-                   !(h->capturing && !h->cap_aux);  // (a captured step that takes turns is one stream's graph)
-  if (aux && !h->capturing && h->pip_concurrent == 2 && h->co_mode == 0) {
+  const bool aux = !(order && h->order_fresh) && !h->stats_on && (h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->lsi_inflight));
+  if (aux && h->pip_concurrent == 2 && h->co_mode == 0) {
     RJ_HIP(h, hipEventRecord(h->ev_order, h->stream));
     RJ_HIP(h, hipStreamWaitEvent(h->aux_stream, h->ev_order, 0));
   }
-  if (h->capturing && order) return fail(h, RJ_E_INVALID, "rj_graph: re-ordered queries cannot be captured");
   const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
-  h->co_measure = !h->capturing && h->pip_concurrent == 2 && h->lsi_inflight && !(order && h->order_fresh) && !h->stats_on && n > 0;
+  h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !(order && h->order_fresh) && !h->stats_on && n > 0;
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
   // in flight together (calls on ONE stream are ordered by the stream)
-  const int pflip = h->capturing ? 0 : h->flip_pip[aux ? 1 : 0];  // (cleared by the previous launch on this stream, see kSchedLsi)
+  const int pflip = h->flip_pip[aux ? 1 : 0];  // (cleared by the previous launch on this stream, see kSchedLsi)
   unsigned long long* sched = h->d_counter + (aux ? kSchedPipAux : kSchedPipMain) + pflip * kSchedBlockWords;
   PipArgs a;
   a.bvh = bvh_view(h->bvh[base_map_id]);
@@ -1473,8 +1433,6 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // terms -- k_pip locates those one scattered handful per wave (the list is in no useful order), which on the gaussian
   // polygons (25 k of 8 M) costs more than the walk saves
   if (walk && h->pip_walk == 1 && seen != ~0ull && (seen * 10 > n * 3 || seen > 16384)) walk = false;
-  if (walk && h->rest_cap[si] < n && h->capturing)
-    return fail(h, RJ_E_INVALID, "rj_graph: run this query once before capturing it (its buffers are allocated on first use)");
   if (walk && h->rest_cap[si] < n) {
     // (both streams' lists at once, the first time a size is seen: a later query on the other stream -- the shared
     //  schedule's trial pair -- must not pay for an allocation inside its measured span)
@@ -1500,7 +1458,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   h->last_walk_points = 1;
   tic(h, RJ_T_PIP_KERNEL, st);
   if (n && walk) {
-    const int wflip = h->capturing ? 0 : h->flip_walk[si];
+    const int wflip = h->flip_walk[si];
     PipArgs w = a;
     w.work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + wflip * kSchedBlockWords);
     w.next_work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + (1 - wflip) * kSchedBlockWords);
@@ -1530,8 +1488,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     }
     if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
     toc(h, RJ_T_PIP_WALK, st);
-    if (!h->capturing) h->flip_walk[si] = 1 - wflip;
-    else h->cap_kinds |= (8 << si) | (2 << si);
+    h->flip_walk[si] = 1 - wflip;
     // second pass: the exact predicate over the candidate lists, and -- the kernel's first blocks -- k_pip's traversal
     // over the points whose list overflowed; that part's grid follows the last count seen for this query size
     // (the list is appended group by group all over the map: the fewer points it holds, the less a wave's points have
@@ -1554,16 +1511,15 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     r.blocks = (uint32_t) rest_blocks;
     h->walk_n[si] = n;
     RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8, r));
-    if (!h->capturing) h->flip_pip[si] = 1 - pflip;
+    h->flip_pip[si] = 1 - pflip;
   } else if (n) {
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
-    if (!h->capturing) h->flip_pip[aux ? 1 : 0] = 1 - pflip;
-    else h->cap_kinds |= 2 << (aux ? 1 : 0);
+    h->flip_pip[aux ? 1 : 0] = 1 - pflip;
   }
   toc(h, RJ_T_PIP_KERNEL, st);
   // a caller-owned array: the estimate the next query over it will go by, behind this query's kernels on their stream
   // (the first queries after a sort or a first sight, then every fourth: one block, a few microseconds)
-  if (h->cur_caller >= 0 && n && !h->capturing) {
+  if (h->cur_caller >= 0 && n) {
     const rj_handle_s::CallerSet& e = h->caller[h->cur_caller];
     if (e.queries <= 2 || e.queries % 4 == 0) RJ_HIP(h, launch_group_extent_tail(st, pts, h->cur_order, n, h->d_est + h->cur_caller));
   }
@@ -2044,124 +2000,6 @@ int rj_last_ms(rj_handle h, int which, float* ms) {
   }
   RJ_HIP(h, hipEventSynchronize(h->ev[which][1]));
   RJ_HIP(h, hipEventElapsedTime(ms, h->ev[which][0], h->ev[which][1]));
-  return RJ_OK;
-}
-
-int rj_graph_begin(rj_handle h, int id) {
-  RJ_CHECK_H(h);
-  if (id < 0 || id >= rj_handle_s::kGraphs) return fail(h, RJ_E_INVALID, "rj_graph_begin: id must be 0..%d", rj_handle_s::kGraphs - 1);
-  if (h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_begin: already capturing");
-  if (h->stats_on) return fail(h, RJ_E_INVALID, "rj_graph_begin: not with the instrumented kernels");
-  if (h->pip_concurrent == 2 && h->co_choice < 0)
-    return fail(h, RJ_E_INVALID, "rj_graph_begin: the kernel schedule is still being measured (\"pip_schedule\" is -1): run more paired steps first");
-  if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipStreamSynchronize(h->stream));
-  RJ_HIP(h, join_aux(h));
-  h->lsi_shared = h->lsi_inflight = false;
-  h->cap_id = id;
-  if (h->graph_exec[id]) { (void) hipGraphExecDestroy(h->graph_exec[id]); h->graph_exec[id] = nullptr; }
-  if (h->graph[id]) { (void) hipGraphDestroy(h->graph[id]); h->graph[id] = nullptr; }
-  if (h->graph_exec_aux[id]) { (void) hipGraphExecDestroy(h->graph_exec_aux[id]); h->graph_exec_aux[id] = nullptr; }
-  if (h->graph_aux[id]) { (void) hipGraphDestroy(h->graph_aux[id]); h->graph_aux[id] = nullptr; }
-  // Beside each other = one graph PER STREAM, replayed on its own stream: the branches of one graph run one after
-  // the other on this ROCm (a fork/join capture of the step took 1.58 ms where the plain launches take 0.95).
-  // Taking turns = the main stream's graph alone.
-  const bool two = h->pip_concurrent == 1 || (h->pip_concurrent == 2 && h->co_choice != 0);
-  RJ_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
-  hipError_t e = hipSuccess;
-  if (two) e = hipStreamBeginCapture(h->aux_stream, hipStreamCaptureModeRelaxed);
-  h->capturing = true;
-  h->cap_aux = two && e == hipSuccess;
-  h->cap_lsi = false;
-  h->cap_kinds = 0;
-  // a replayed step cannot alternate between two counter sets (its arguments are frozen): it uses set 0 of every kind
-  // and clears them first (the kernels still clear set 1, which nothing reads); each stream clears what its kernels use
-  if (e == hipSuccess) e = hipMemsetAsync(h->d_counter, 0, 16, h->stream);                                // LSI result counts
-  if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kRestCountWord, 0, 16, h->stream);               // the main stream's rest counts
-  if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kSlowCountWord, 0, 16, h->stream);               // k_lsi_points' list counts
-  for (size_t blk : {kSchedLsi, kSchedPipMain, kSchedWalkMain})
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + blk, 0, 8 * 128, h->stream);                   // 8 counters, 128 B apart
-  if (h->cap_aux) {
-    if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + kRestCountWord + 2, 0, 16, h->aux_stream);
-    for (size_t blk : {kSchedPipAux, kSchedWalkAux})
-      if (e == hipSuccess) e = hipMemsetAsync(h->d_counter + blk, 0, 8 * 128, h->aux_stream);
-  }
-  if (e != hipSuccess) {
-    hipGraph_t g = nullptr;
-    (void) hipStreamEndCapture(h->stream, &g);
-    if (g) (void) hipGraphDestroy(g);
-    if (h->cap_aux) { g = nullptr; (void) hipStreamEndCapture(h->aux_stream, &g); if (g) (void) hipGraphDestroy(g); }
-    h->capturing = h->cap_aux = false;
-    RJ_HIP(h, e);
-  }
-  return RJ_OK;
-}
-
-int rj_graph_end(rj_handle h) {
-  RJ_CHECK_H(h);
-  if (!h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_end: rj_graph_begin first");
-  hipError_t e = hipSuccess;
-  // the step's one read-back: the intersection count, into pinned memory (rj_graph_lsi_count reads it after the stream is done)
-  if (h->cap_lsi) e = hipMemcpyAsync(h->h_pinned, h->d_counter + h->count_word, 8, hipMemcpyDeviceToHost, h->stream);
-  hipGraph_t g = nullptr, ga = nullptr;
-  hipError_t ec = hipStreamEndCapture(h->stream, &g);
-  if (h->cap_aux) {
-    const hipError_t ea = hipStreamEndCapture(h->aux_stream, &ga);
-    if (ec == hipSuccess) ec = ea;
-  }
-  h->capturing = false;
-  h->lsi_shared = h->lsi_inflight = false;
-  h->co_measure = false;
-  h->aux_pending = false;
-  if (e == hipSuccess) e = ec;
-  if (e != hipSuccess || !g || (h->cap_aux && !ga)) {
-    if (g) (void) hipGraphDestroy(g);
-    if (ga) (void) hipGraphDestroy(ga);
-    h->cap_aux = false;
-    return fail(h, RJ_E_HIP, "rj_graph_end: capture failed: %s", hipGetErrorString(e));
-  }
-  h->cap_aux = false;
-  h->graph[h->cap_id] = g;
-  h->graph_aux[h->cap_id] = ga;
-  h->graph_kinds[h->cap_id] = h->cap_kinds;
-  RJ_HIP(h, hipGraphInstantiate(&h->graph_exec[h->cap_id], g, nullptr, nullptr, 0));
-  if (ga) RJ_HIP(h, hipGraphInstantiate(&h->graph_exec_aux[h->cap_id], ga, nullptr, nullptr, 0));
-  return RJ_OK;
-}
-
-int rj_graph_launch(rj_handle h, int id) {
-  RJ_CHECK_H(h);
-  if (id < 0 || id >= rj_handle_s::kGraphs || !h->graph_exec[id] || h->capturing) return fail(h, RJ_E_INVALID, "rj_graph_launch: no captured step %d", id);
-  if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipGraphLaunch(h->graph_exec[id], h->stream));
-  // the replay runs on counter set 0 of every kind it holds and leaves set 1 cleared: a plain launch that follows must
-  // use set 1 (it would find set 0 exhausted, do nothing and report the replay's count)
-  const int kinds = h->graph_kinds[id];
-  if (kinds & 1) { h->flip_lsi = 1; h->count_word = 0; }
-  for (int k = 0; k < 2; k++) {
-    if (kinds & (2 << k)) h->flip_pip[k] = 1;
-    if (kinds & (8 << k)) h->flip_walk[k] = 1;
-  }
-  if (kinds & 32) h->flip_slow = 1;
-  if (h->graph_exec_aux[id]) {
-    RJ_HIP(h, hipGraphLaunch(h->graph_exec_aux[id], h->aux_stream));
-    h->aux_pending = true;  // (rj_sync / rj_graph_lsi_count + rj_sync join it)
-  }
-  return RJ_OK;
-}
-
-int rj_graph_lsi_count(rj_handle h, uint64_t capacity, uint64_t* n_found) {
-  RJ_CHECK_H(h);
-  bool any = false;
-  for (int g = 0; g < rj_handle_s::kGraphs; g++) any = any || h->graph_exec[g];
-  if (!any) return fail(h, RJ_E_INVALID, "rj_graph_lsi_count: no captured step");
-  if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipStreamSynchronize(h->stream));
-  const uint64_t n = h->h_pinned[0];
-  if (n_found) *n_found = n;
-  if (int r = check_fault(h)) return r;
-  if (n > capacity)
-    return fail(h, RJ_E_OVERFLOW, "intersection queue overflow: %llu found, capacity %llu", (unsigned long long) n, (unsigned long long) capacity);
   return RJ_OK;
 }
 

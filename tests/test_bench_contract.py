@@ -34,7 +34,11 @@ def test_committed_bench_line_has_the_contract_fields():
     n_s = 28793160
     assert abs(d["value"] - n_s / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 0.01
     # the harder pairs ride in the same line, each with its own roofline and CPU baseline
-    assert [s["metric"].split(", ")[1] for s in d["secondary"]] == ["USCounty |><| NestedBlockGroup", "WaterBodies |><| BlockGroup"]
+    assert [s["metric"].split(", ")[1] for s in d["secondary"]][:2] == ["USCounty |><| NestedBlockGroup", "WaterBodies |><| BlockGroup"]
+    if "r04" in os.path.basename(_latest_bench()) or len(d["secondary"]) > 2:   # round 4: a lake-shaped base map rides along
+        assert d["secondary"][2]["metric"].split(", ")[1] == "WaterBodiesLike |><| BlockGroup"
+        assert d["build_index_ms"] < 10 and d["rebuild_index_ms"] < d["build_index_ms"]   # the FIRST build of the map, on the device
+        assert d["pip_caller_array"]["equals_map_owned_results"] is True and d["pip_caller_array"]["vs_map_owned"] < 1.06
     for s in d["secondary"]:
         assert s["value"] > 0 and "roofline" in s and "cpu_baseline" in s and s["config"]["schedule_settled_before_timing"] is True
 

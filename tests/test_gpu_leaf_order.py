@@ -97,8 +97,8 @@ def test_short_rings_share_leaves(oracle):
             #  far apart; sharing forbidden -- the fall-back)
             for solo, spread, used in ((0, 1000, 1), (0, 0, None), (1, 0, 0)):
                 h.set_option("leaf_order", 1)
-                h.set_option("debug_pack_solo", solo)
-                h.set_option("debug_pack_spread", spread)
+                h.set_debug_option("pack_solo", solo)
+                h.set_debug_option("pack_spread", spread)
                 pairs, closest, face = _run(h, 0, m[1], 8 * len(want_pairs) + 1024)
                 if used is not None:
                     assert h.get_option("leaf_order_used0") == used, (what, solo, spread)

@@ -473,10 +473,11 @@ def test_async_query_leaves_complete_records(oracle, lattice_pair):
     assert np.array_equal(got["x_num"], ref["x_num"]) and np.array_equal(got["y_num"], ref["y_num"])
 
 
-def test_captured_step_replays_the_same_results(oracle):
-    """rj_graph_begin .. rj_graph_end captures a step (LSI + records + PIP, both streams, one graph per stream) and
-    rj_graph_launch replays it: results of every replay equal the plain launches' and the oracle's, for the schedule
-    that shares the chip and for taking turns; what cannot be captured says so."""
+def test_pipelined_steps_equal_the_oracle(oracle):
+    """Step k + 1 launched before step k's count is looked at (rj_lsi_count_async / rj_lsi_count_wait, two sets of result
+    buffers): what bench.py's pipelined loop and an N > 1 job run.  Every step's pairs, records, closest eids and faces
+    against the oracle, for the schedule that shares the chip, for "auto" and for taking turns; then a plain
+    synchronised query behind the pipelined ones, other buffers and another range."""
     ctx = maps.Context([synth.lattice_map(9, 120, 31), synth.lattice_map(21, 50, 32)]).load()
     b, q = ctx.maps
     m0, m1 = _omap(oracle, b), _omap(oracle, q)
@@ -487,68 +488,54 @@ def test_captured_step_replays_the_same_results(oracle):
         h.upload_map(0, b.pts, b.row_index, b.left, b.right)
         h.upload_map(1, q.pts, q.row_index, q.left, q.right)
         h.build_lbvh(0)
-        h.set_option("query_order", 0)  # (re-ordered queries are never captured: shared scratch)
         cap = 4 * len(want_pairs) + 64
-        pairs, xs = h.alloc(8 * cap), h.alloc(48 * cap)
-        closest, faces = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+        pairs = [h.alloc(8 * cap) for _ in range(2)]
+        xs = [h.alloc(48 * cap) for _ in range(2)]
+        closest = [h.alloc(4 * q.n_points) for _ in range(2)]
+        faces = [h.alloc(4 * q.n_points) for _ in range(2)]
 
-        def enqueue():
-            h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs)
-            h.pip_query(0, 1, None, 0, q.n_points, closest, faces, sync=False)
-            h.lsi_points_async(pairs, cap, xs)
+        def check(k, n, what):
+            assert n == len(want_pairs), what
+            got = pairs[k].to_host(np.uint32, 2 * n).reshape(-1, 2)
+            assert np.array_equal(oracle.sort_pairs(got.copy()), want_pairs), what
+            rec = xs[k].to_host(_capi.XSECT_DTYPE, n)
+            ref = oracle.lsi_points(m0, m1, np.ascontiguousarray(rec["eid"]))
+            assert np.array_equal(rec["eid"], got) and np.array_equal(rec["x_num"], ref["x_num"]) and np.array_equal(rec["y_num"], ref["y_num"]), what
+            assert np.array_equal(closest[k].to_host(np.uint32), want_eids), what
+            assert np.array_equal(faces[k].to_host(np.int32), m0.face_ids(want_eids)), what
 
-        with pytest.raises(_capi.RayJoinError):  # nothing has run yet: the PIP passes' buffers do not exist
-            h.graph_begin(0)
-            try:
-                enqueue()
-            finally:
-                h.graph_end()
-        enqueue(); h.lsi_query_finish(cap); h.sync()
-        for conc in (1, 0):
+        for conc in (1, 2, 0):
             h.set_option("pip_concurrent", conc)
-            enqueue(); n = h.lsi_query_finish(cap); h.sync()
-            assert n == len(want_pairs)
-            h.graph_begin(conc)
-            enqueue()
-            with pytest.raises(_capi.RayJoinError):
-                h.sync()  # a sync cannot be captured
-            h.graph_end()
-            for rep in range(3):
-                closest.from_host(np.zeros(q.n_points, dtype=np.uint32))
-                h.graph_launch(conc)
-                n = h.graph_lsi_count(cap)
+            for timers in (1, 0):
+                h.set_option("timers", timers)
+                for k in (0, 1):
+                    closest[k].from_host(np.full(q.n_points, 0xDEADBEEF, dtype=np.uint32))
+                steps = 7
+                for j in range(steps):
+                    k = j % 2
+                    h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs[k])
+                    h.pip_query(0, 1, None, 0, q.n_points, closest[k], faces[k], sync=False)
+                    h.lsi_points_async(pairs[k], cap, xs[k])
+                    h.lsi_count_async(k)
+                    if j > 0:
+                        n = h.lsi_count_wait(1 - k, cap)
+                        if j in (1, steps - 1):   # (the buffers of step j - 1 are complete once step j's successor... is not yet launched: look now)
+                            h.sync()
+                            check(1 - k, n, (conc, timers, j - 1))
+                n = h.lsi_count_wait((steps - 1) % 2, cap)
                 h.sync()
-                assert n == len(want_pairs)
-                assert np.array_equal(closest.to_host(np.uint32), want_eids), (conc, rep)
-                assert np.array_equal(faces.to_host(np.int32), m0.face_ids(want_eids))
-                got = pairs.to_host(np.uint32, 2 * n).reshape(-1, 2)
-                assert np.array_equal(oracle.sort_pairs(got.copy()), want_pairs)
-            assert h.last_ms(_capi.RJ_T_PIP_KERNEL) > 0 and h.last_ms(_capi.RJ_T_LSI_KERNEL) > 0
-            # a plain query right behind a replay (the replay used counter set 0 of every kind and left set 1 cleared):
-            # other buffers, another range -- it must do its own work, not report the replay's
+                check((steps - 1) % 2, n, (conc, timers, "last"))
+            h.set_option("timers", 1)
+            # a plain query behind them
             half_e, half_p = q.n_edges // 2, q.n_points // 3
-            pairs2, xs2 = h.alloc(8 * cap), h.alloc(48 * cap)
-            closest2, faces2 = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
-            closest2.from_host(np.full(q.n_points, 7, dtype=np.uint32))
-            h.lsi_query_async(0, 1, 0, half_e, cap, pairs2)
-            h.pip_query(0, 1, None, 0, half_p, closest2, faces2, sync=False)
-            h.lsi_points_async(pairs2, cap, xs2)
-            n2 = h.lsi_query_finish(cap); h.sync()
+            n2 = h.lsi_query(0, 1, 0, half_e, cap, pairs[0])
+            h.pip_query(0, 1, None, 0, half_p, closest[0], faces[0])
             want_half = want_pairs[want_pairs[:, 1] < half_e]
-            assert n2 == len(want_half), (conc, n2, len(want_half))
-            assert np.array_equal(oracle.sort_pairs(pairs2.to_host(np.uint32, 2 * n2).reshape(-1, 2).copy()), want_half)
-            assert np.array_equal(closest2.to_host(np.uint32)[:half_p], want_eids[:half_p])
-            assert np.array_equal(faces2.to_host(np.int32)[:half_p], m0.face_ids(want_eids[:half_p]))
-            got2 = xs2.to_host(_capi.XSECT_DTYPE, n2)
-            ref2 = oracle.lsi_points(m0, m1, np.ascontiguousarray(got2["eid"]))
-            assert np.array_equal(got2["x_num"], ref2["x_num"]) and np.array_equal(got2["y_num"], ref2["y_num"])
-            # ... and a replay behind the plain query still equals the oracle
-            h.graph_launch(conc)
-            assert h.graph_lsi_count(cap) == len(want_pairs)
-            h.sync()
-            assert np.array_equal(closest.to_host(np.uint32), want_eids)
+            assert n2 == len(want_half)
+            assert np.array_equal(oracle.sort_pairs(pairs[0].to_host(np.uint32, 2 * n2).reshape(-1, 2).copy()), want_half)
+            assert np.array_equal(closest[0].to_host(np.uint32)[:half_p], want_eids[:half_p])
         with pytest.raises(_capi.RayJoinError):
-            h.graph_launch(3)  # never captured
+            h.lsi_count_wait(0, cap)  # nothing in flight
     finally:
         h.close()
 

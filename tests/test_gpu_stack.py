@@ -104,7 +104,7 @@ def test_stack_overflow_is_reported_not_corrupted(oracle):
     pairs = h.alloc(8 * cap)
     closest = h.alloc(4 * q.n_points)
     h.set_option("stats", 1)
-    h.set_option("debug_stack_cap", 1)
+    h.set_debug_option("stack_cap", 1)
     with pytest.raises(_capi.RayJoinError) as ei:
         h.lsi_query(0, 1, 0, q.n_edges, cap, pairs)
     assert ei.value.code == _capi.RJ_E_INTERNAL and "k_lsi" in str(ei.value)
@@ -117,7 +117,7 @@ def test_stack_overflow_is_reported_not_corrupted(oracle):
     assert ei.value.code == _capi.RJ_E_INTERNAL
     for stats in (1, 0):
         h.set_option("stats", stats)
-        h.set_option("debug_stack_cap", 1 << 30)
+        h.set_debug_option("stack_cap", 1 << 30)
         n = h.lsi_query(0, 1, 0, q.n_edges, cap, pairs)
         h.sort_pairs(pairs, n)
         assert np.array_equal(pairs.to_host(np.uint32, 2 * n).reshape(-1, 2), want)

@@ -36,7 +36,7 @@ def device_runs(pts, row_index, cap=0):
         h.upload_map(0, pts, row_index, np.zeros(nc, dtype=np.int64), np.ones(nc, dtype=np.int64))
         h.set_option("leaf_order", 1)
         if cap:
-            h.set_option("debug_run_cap", cap)
+            h.set_debug_option("run_cap", cap)
         h.build_lbvh(0)
         return h.map_runs(0), (h.get_option("stitch_rounds"), h.get_option("stitch_loop_ends"))
     finally:

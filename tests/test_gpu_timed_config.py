@@ -7,8 +7,9 @@ points per lane, then k_pip_exact) + rj_lsi_points_async with the count read on 
 "pip_concurrent" 2 settles on during the reference's five warm-up queries (run_query.cu:292-296).  Here that step runs
 verbatim -- bench.py's call sequence, five warm-up pairs, then a pair on the settled schedule -- on USCounty x BlockGroup
 (the headline) and USCounty x NestedBlockGroup, and pairs, 48-byte records, closest eids and face ids are compared with
-oracle.lsi_grid / pip_grid (lsi_lbvh.h:27-98, pip_lbvh.h:25-142 semantics as -mode=grid computes them); then the same
-step captured by rj_graph_begin/end and replayed."""
+oracle.lsi_grid / pip_grid (lsi_lbvh.h:27-98, pip_lbvh.h:25-142 semantics as -mode=grid computes them); then bench.py's
+PIPELINED loop (step k + 1 launched before step k's count is read: rj_lsi_count_async / rj_lsi_count_wait, two sets of
+result buffers), whose last two steps are compared the same way."""
 import numpy as np
 import pytest
 
@@ -96,21 +97,38 @@ def test_the_timed_step_equals_the_oracle_at_full_size(oracle, query_name, min_x
             _check(oracle, m0, None, want, want_e, n, pairs, xs, closest, faces, (query_name, "timers", timers))
         h.set_option("timers", 1)
 
-        # --- the same step as a captured graph (one per stream), replayed twice
-        h.graph_begin(0)
-        h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs)
-        h.pip_query(0, 1, None, 0, q.n_points, closest, faces, sync=False)
-        h.lsi_points_async(pairs, cap, xs)
-        h.graph_end()
-        for rep in range(2):
-            wipe()
-            h.graph_launch(0)
-            n = h.graph_lsi_count(cap)
-            h.sync()
-            _check(oracle, m0, None, want, want_e, n, pairs, xs, closest, faces, (query_name, "graph", rep))
-        # ... and a plain step behind the replays
+        # --- bench.py::pipelined_steps: no host sync at the end of a step, two buffer sets, timers off
+        pairs2, xs2 = h.alloc(8 * cap), h.alloc(48 * cap)
+        closest2, faces2 = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+        bufs = [(pairs, xs, closest, faces), (pairs2, xs2, closest2, faces2)]
+        wipe()
+        closest2.from_host(np.full(q.n_points, 0xDEADBEEF, dtype=np.uint32))
+        h.set_option("timers", 0)
+        steps, counts = 6, {}
+        for j in range(steps):
+            k = j % 2
+            P, X, C_, F = bufs[k]
+            h.lsi_query_async(0, 1, 0, q.n_edges, cap, P)
+            early = h.get_option("pip_schedule") in (1, 2)
+            if early:
+                h.pip_query(0, 1, None, 0, q.n_points, C_, F, sync=False)
+            h.lsi_points_async(P, cap, X)
+            h.lsi_count_async(k)
+            if not early:
+                h.pip_query(0, 1, None, 0, q.n_points, C_, F, sync=False)
+            if j > 0:
+                counts[j - 1] = h.lsi_count_wait(1 - k, cap)
+        counts[steps - 1] = h.lsi_count_wait((steps - 1) % 2, cap)
+        h.sync()
+        h.set_option("timers", 1)
+        assert h.get_option("lsi_last_segments") == 2 and h.get_option("pip_last_walk_points") == 2
+        for j in (steps - 2, steps - 1):   # the last step into either buffer set
+            P, X, C_, F = bufs[j % 2]
+            _check(oracle, m0, None, want, want_e, counts[j], P, X, C_, F, (query_name, "pipelined", j))
+        assert all(n == len(want) for n in counts.values())
+        # ... and a plain step behind the pipelined ones
         wipe()
         n = _step(h, q, cap, pairs, xs, closest, faces)
-        _check(oracle, m0, None, want, want_e, n, pairs, xs, closest, faces, (query_name, "after graph"))
+        _check(oracle, m0, None, want, want_e, n, pairs, xs, closest, faces, (query_name, "after the pipelined steps"))
     finally:
         h.close()

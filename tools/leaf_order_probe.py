@@ -22,12 +22,12 @@ first = None
 for var in a.variants.split(","):
     f = [int(x) for x in var.split(":")]
     order, solo, rcap, spread = f[0], (f[1] if len(f) > 1 else 0), (f[2] if len(f) > 2 else 0), (f[3] if len(f) > 3 else 0)
-    if rcap != h.get_option("debug_run_cap"):  # (the runs are cut once per uploaded map: cut them again)
+    if rcap != h.get_debug_option("run_cap"):  # (the runs are cut once per uploaded map: cut them again)
         h.upload_map(0, b.pts, b.row_index, b.left, b.right)
-    h.set_option("debug_run_cap", rcap)
+    h.set_debug_option("run_cap", rcap)
     h.set_option("leaf_order", order)
-    h.set_option("debug_pack_solo", solo)
-    h.set_option("debug_pack_spread", spread)
+    h.set_debug_option("pack_solo", solo)
+    h.set_debug_option("pack_spread", spread)
     h.build_lbvh(0); first_ms = h.last_ms(_capi.RJ_T_BUILD); h.build_lbvh(0)
     order = var
     out = {"pair": "%s x %s" % (a.base, a.query), "variant": var, "first_build_ms": round(first_ms, 3), "build_ms": round(h.last_ms(_capi.RJ_T_BUILD), 3),

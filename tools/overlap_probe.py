@@ -20,7 +20,7 @@ cap = int(0.1 * (b.n_edges + q.n_edges)) + 1024
 pairs = h.alloc(8 * cap); xs = h.alloc(48 * cap); closest = h.alloc(4 * q.n_points); faces = h.alloc(4 * q.n_points)
 for conc in (0, 1):
     for mb in (1 << 20, 1024, 768, 512):
-        h.set_option("pip_concurrent", conc); h.set_option("max_blocks", mb)
+        h.set_option("pip_concurrent", conc); h.set_debug_option("max_blocks", mb)
         ts = []
         for r in range(a.reps + 5):
             t0 = time.perf_counter()

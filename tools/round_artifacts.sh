@@ -25,7 +25,5 @@ for p in "USCounty BlockGroup" "USCounty Zipcode" "USCounty NestedBlockGroup" "W
 done
 echo "leaf order done"
 timeout -k 10 200 python3 tools/schedule_probe.py --steps 8 2>/dev/null | grep "^{" > gpurun_out/${TAG}_schedule_probe.txt
-timeout -k 10 200 python3 tools/graph_probe.py 2>/dev/null | grep "^{" > gpurun_out/${TAG}_graph_probe.txt
-timeout -k 10 200 python3 tools/graph_probe.py --shards 8 2>/dev/null | grep "^{" >> gpurun_out/${TAG}_graph_probe.txt
 timeout -k 10 200 python3 tools/build_probe.py 2>/dev/null | tail -12 > gpurun_out/${TAG}_build_probe.txt
 echo "all done"

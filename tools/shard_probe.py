@@ -21,7 +21,7 @@ cap = int(0.1 * (b.n_edges + q.n_edges)) + 1024
 pairs = h.alloc(8 * cap); closest = h.alloc(4 * q.n_points); faces = h.alloc(4 * q.n_points)
 for c in a.chunks.split(","):
     for gl in a.lanes.split(","):
-        h.set_option("chunk_groups", int(c)); h.set_option("group_lanes", int(gl))
+        h.set_debug_option("chunk_groups", int(c)); h.set_debug_option("group_lanes", int(gl))
         l, p = [], []
         for _ in range(a.reps):
             n = h.lsi_query(0, 1, e0, e1, cap, pairs); l.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))

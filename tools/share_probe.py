@@ -37,5 +37,5 @@ print(json.dumps({"schedule": "turns", **run(False)}), flush=True)
 h.set_option("pip_concurrent", 1)
 for lb in [int(v) for v in a.lsi.split(",")]:
     for pb in [int(v) for v in a.pip.split(",")]:
-        h.set_option("lsi_share_set", lb); h.set_option("pip_share_set", pb)
+        h.set_debug_option("lsi_share_blocks", lb); h.set_debug_option("pip_share_blocks", pb)
         print(json.dumps({"schedule": "shared", "lsi_blocks": lb, "pip_blocks": pb, **run(True)}), flush=True)

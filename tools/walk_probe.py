@@ -21,7 +21,7 @@ for mode in (0, 2):
     h.set_option("pip_walk", mode)
     closest = h.alloc(4 * q.n_points); face = h.alloc(4 * q.n_points)
     for mb in ([int(v) for v in a.max_blocks.split(",")] if a.max_blocks else [1 << 20]):
-        h.set_option("max_blocks", mb)
+        h.set_debug_option("max_blocks", mb)
         tot, walk = [], []
         for _ in range(a.reps):
             h.pip_query(0, 1, None, 0, q.n_points, closest, face)
@@ -31,13 +31,13 @@ for mode in (0, 2):
         print(json.dumps({"pip_walk": mode, "max_blocks": mb, "pip_ms": round(float(np.median(tot)), 4),
                           "walk_ms": round(float(np.median(walk)), 4) if walk else None,
                           "rest": h.get_option("pip_rest") if mode else None, "points": q.n_points}), flush=True)
-    h.set_option("max_blocks", 1 << 20)
+    h.set_debug_option("max_blocks", 1 << 20)
     res[mode] = (closest.to_host(np.uint32), face.to_host(np.int32))
 print(json.dumps({"equal_eids": bool(np.array_equal(res[0][0], res[2][0])), "equal_faces": bool(np.array_equal(res[0][1], res[2][1]))}))
 # instrumented kernels: visit counts and cycle stamps of k_pip and of k_pip_walk (sums over waves)
 ngroups = (q.n_points + 63) // 64
 for mb in (() if a.no_stats else (256, 1 << 20)):
-    h.set_option("max_blocks", mb)
+    h.set_debug_option("max_blocks", mb)
     for mode in (0, 2):
         h.set_option("pip_walk", mode); h.set_option("stats", 1)
         h.pip_query(0, 1, None, 0, q.n_points, closest, face)
