@@ -57,6 +57,12 @@ struct BvhState {
   uint32_t* occ = nullptr;
   uint32_t* sky = nullptr;  // skyline of the map (rj_device.h kSkyShift): what the PIP kernels prove a miss with
   bool use_sky = false;     // ... filled and used (maps of isolated rings)
+  // the column index (rj_device.h DeviceStrips; maps of isolated rings): what the PIP query's first pass runs on instead
+  // of the tree
+  uint32_t *strip_begin = nullptr, *strip_slot = nullptr, *strip_tall = nullptr;
+  uint64_t* strip_key = nullptr;
+  uint64_t strip_entries = 0, strip_cap = 0;
+  bool strips_built = false;
   QBox* lvl[kMaxLevels] = {nullptr};  // boxes of level l, then one sibling-order word per node (rj_device.h)
   uint64_t nlvl[kMaxLevels] = {0};
   uint64_t alloc[kMaxLevels] = {0};
@@ -218,6 +224,10 @@ struct rj_handle_s {
   int debug_pack_solo = 0;   // experiments: a run longer than this never shares its leaf (0: the default, 48)
   int debug_pack_spread = 0; // experiments: how many times larger than its runs a shared leaf may be (0: the default, 8)
   uint32_t stitch_stats[4] = {0, 0, 0, 0};  // the last run cutting: ranking rounds, incidences on closed loops, rounds of the second ranking, closed chains
+  char* strip_scratch = nullptr;  // grow-only temporaries of the column index's build
+  size_t strip_scratch_bytes = 0;
+  int pip_columns = -1;      // "pip_columns": -1 auto (maps of isolated rings), 0 never, 1 always -- the column index of the NEXT rj_build_lbvh
+  int last_columns = 0;      // the last PIP query's first pass ran on the column index
   int skyline = -1;          // "skyline": -1 auto (maps of isolated rings), 0 never, 1 always -- what the NEXT rj_build_lbvh does
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
@@ -302,6 +312,7 @@ void free_grid(GridState& g) {
 
 void free_bvh(BvhState& b) {
   (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
+  (void) hipFree(b.strip_begin); (void) hipFree(b.strip_slot); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_key);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
@@ -314,6 +325,8 @@ DeviceBvh bvh_view(const BvhState& b) {
     d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
   }
   d.top = b.top; d.n0 = b.n0;
+  d.strips.begin = b.strips_built ? b.strip_begin : nullptr;
+  d.strips.key = b.strip_key; d.strips.slot = b.strip_slot; d.strips.tall = b.strip_tall;
   return d;
 }
 
@@ -477,7 +490,8 @@ int rj_create(int device_id, rj_handle* out) {
   // load every code object of the library now (a kernel's first launch loads its file's code object: milliseconds
   // that would otherwise land in the first upload, the first index build and the first query)
   ok = ok && warm_query_kernels(h->stream) == hipSuccess && warm_grid_kernels(h->stream) == hipSuccess &&
-       warm_stitch_kernels(h->stream) == hipSuccess && hipStreamSynchronize(h->stream) == hipSuccess;
+       warm_stitch_kernels(h->stream) == hipSuccess && warm_strip_kernels(h->stream) == hipSuccess &&
+       hipStreamSynchronize(h->stream) == hipSuccess;
   if (!ok) { delete h; return RJ_E_HIP; }
   *out = h;
   return RJ_OK;
@@ -500,6 +514,7 @@ int rj_destroy(rj_handle h) {
   for (int k = 0; k < 2; k++) if (h->ev_count[k]) (void) hipEventDestroy(h->ev_count[k]);
   if (h->ev_order) (void) hipEventDestroy(h->ev_order);
   (void) hipFree(h->arena);
+  (void) hipFree(h->strip_scratch);
   if (h->comm) (void) rj_comm_destroy(h);
   (void) hipStreamDestroy(h->own_stream);
   (void) hipStreamDestroy(h->aux_stream);
@@ -582,6 +597,10 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "stitch_rounds")) *value = h->stitch_stats[0];      // the last run cutting: pointer-jumping rounds that had work
   else if (!strcmp(name, "stitch_loop_ends")) *value = h->stitch_stats[1];   // ... chain ends on closed loops of paired chains
   else if (!strcmp(name, "skyline")) *value = h->skyline;
+  else if (!strcmp(name, "pip_columns")) *value = h->pip_columns;
+  else if (!strcmp(name, "pip_columns_used0") || !strcmp(name, "pip_columns_used1")) *value = h->bvh[name[16] - '0'].strips_built ? 1 : 0;
+  else if (!strcmp(name, "pip_column_entries0") || !strcmp(name, "pip_column_entries1")) *value = (int64_t) h->bvh[name[18] - '0'].strip_entries;
+  else if (!strcmp(name, "pip_last_columns")) *value = h->last_columns;
   else if (!strcmp(name, "skyline_used0") || !strcmp(name, "skyline_used1")) *value = h->bvh[name[12] - '0'].use_sky ? 1 : 0;
   else if (!strcmp(name, "closed_chains0") || !strcmp(name, "closed_chains1")) *value = (int64_t) h->map[name[13] - '0'].closed_chains;
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
@@ -612,6 +631,11 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "skyline")) {
     if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "skyline: -1 auto (maps of isolated rings), 0 never, 1 always");
     h->skyline = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "pip_columns")) {
+    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "pip_columns: -1 auto (maps of isolated rings), 0 never, 1 always");
+    h->pip_columns = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "lsi_segments")) {
@@ -833,6 +857,73 @@ static int ensure_sort_scratch(rj_handle h, uint64_t n) {
   return RJ_OK;
 }
 
+// the column index of an index whose leaves are built (b.box0, b.seid): rj_strip.hip.  Temporaries come out of one
+// grow-only scratch block of the handle and the index's own arrays are kept while they are large enough: a rebuild
+// allocates nothing (the first version paid six hipMalloc / hipFree of hundreds of MB per build: 50-120 ms).
+static int build_strips(rj_handle h, BvhState& b) {
+  b.strips_built = false;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+  auto scratch = [&](size_t bytes) -> int {
+    if (bytes <= h->strip_scratch_bytes) return RJ_OK;
+    (void) hipFree(h->strip_scratch);
+    h->strip_scratch = nullptr; h->strip_scratch_bytes = 0;
+    RJ_HIP(h, hipMalloc((void**) &h->strip_scratch, bytes));
+    h->strip_scratch_bytes = bytes;
+    return RJ_OK;
+  };
+  size_t scan_bytes = 0;
+  RJ_HIP(h, launch_strip_count(h->stream, nullptr, nullptr, b.n0p, nullptr, nullptr, nullptr, scan_bytes, nullptr));
+  const size_t cnt_bytes = up(4 * (b.n0p + 1));
+  // pass 1 needs: cnt, offs, flag, scan temp; pass 2 adds key_tmp, slot_tmp, sort temp (sized once the total is known:
+  // an upper bound first -- twice the slots covers every map whose segments are not wider than a strip or two)
+  if (int r = scratch(2 * cnt_bytes + 256 + up(scan_bytes))) return r;
+  uint32_t* cnt = (uint32_t*) h->strip_scratch;
+  uint32_t* offs = (uint32_t*) (h->strip_scratch + cnt_bytes);
+  uint32_t* flag = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes);
+  void* temp = h->strip_scratch + 2 * cnt_bytes + 256;
+  RJ_HIP(h, hipMemsetAsync(flag, 0, 4, h->stream));
+  size_t tb = scan_bytes;
+  RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, cnt, offs, temp, tb, flag));
+  RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 30, offs + b.n0p, 4, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipMemcpyAsync((uint32_t*) (h->h_pinned + 30) + 1, flag, 4, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  const uint32_t total = (uint32_t) h->h_pinned[30], bad = (uint32_t) (h->h_pinned[30] >> 32);
+  if (bad || total == 0) return RJ_OK;  // (a segment spanning more than kStripMaxSpan strips: the tree alone serves this map)
+  size_t sort_bytes = 0;
+  RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, b.n0p, total, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
+  const size_t need = 2 * cnt_bytes + 256 + up(8 * (size_t) total) + up(4 * (size_t) total) + up(sort_bytes);
+  if (need > h->strip_scratch_bytes) {
+    // (the counts live in the scratch block that is about to move: count again into the new one -- first build of a
+    //  larger map only)
+    if (int r = scratch(need + need / 8)) return r;
+    cnt = (uint32_t*) h->strip_scratch; offs = (uint32_t*) (h->strip_scratch + cnt_bytes); flag = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes);
+    temp = h->strip_scratch + 2 * cnt_bytes + 256;
+    tb = scan_bytes;
+    RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, cnt, offs, temp, tb, flag));
+  }
+  uint64_t* key_tmp = (uint64_t*) (h->strip_scratch + 2 * cnt_bytes + 256);
+  uint32_t* slot_tmp = (uint32_t*) ((char*) key_tmp + up(8 * (size_t) total));
+  temp = (char*) slot_tmp + up(4 * (size_t) total);
+  if (b.strip_cap < total) {
+    (void) hipFree(b.strip_slot); (void) hipFree(b.strip_key);
+    b.strip_slot = nullptr; b.strip_key = nullptr; b.strip_cap = 0;
+    const uint64_t cap = (uint64_t) total + total / 16;
+    if (int r = dev_alloc(h, &b.strip_key, cap)) return r;
+    if (int r = dev_alloc(h, &b.strip_slot, cap)) return r;
+    b.strip_cap = cap;
+  }
+  if (!b.strip_tall) {
+    if (int r = dev_alloc(h, &b.strip_tall, (uint64_t) kStrips)) return r;
+    if (int r = dev_alloc(h, &b.strip_begin, (uint64_t) kStrips + 1)) return r;
+  }
+  tb = sort_bytes;
+  RJ_HIP(h, launch_strip_fill(h->stream, b.box0, cnt, offs, b.n0p, total, b.strip_key, b.strip_slot, key_tmp, slot_tmp, b.strip_tall,
+                              b.strip_begin, temp, tb));
+  b.strip_entries = total;
+  b.strips_built = true;
+  return RJ_OK;
+}
+
 int rj_build_lbvh(rj_handle h, int base_map_id) {
   RJ_CHECK_H(h);
   if (base_map_id < 0 || base_map_id > 1 || !h->map[base_map_id].present)
@@ -1004,10 +1095,16 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if ((e = launch_sibling_order(h->stream, b.lvl[l], b.alloc[l], (uint64_t*) (b.lvl[l] + b.alloc[l]))) != hipSuccess) break;
     if (e != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEVELS);
-    toc(h, RJ_T_BUILD);
-    e = hipStreamSynchronize(h->stream);
   } while (0);
   RJ_HIP(h, e);
+  // The column index (rj_device.h DeviceStrips), where the tree is at its worst for upward rays: maps of isolated rings
+  // (the criterion of the skyline).  Two passes over the sorted slots around a radix sort of the (strip, y0) entries.
+  b.strips_built = false;
+  if (h->pip_columns == 1 || (h->pip_columns < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc)) {
+    if (int r = build_strips(h, b)) return r;
+  }
+  toc(h, RJ_T_BUILD);
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
   b.built = true;
   co_reset(h);
   h->h_rest[0] = h->h_rest[1] = ~0ull;  // (a new index: the "auto" decision to drop the walk is taken again)
@@ -1369,7 +1466,11 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   if (int r = set_device(h)) return r;
   if (h->stats_on) RJ_HIP(h, hipMemsetAsync(h->d_stats, 0, 128, h->stream));
   const uint32_t* order = nullptr;
-  if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
+  // (a base map with a column index answers every point on its own -- nothing is shared between the points of a wave,
+  //  so a scattered query set needs no re-ordering there)
+  const bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && !h->stats_on;
+  if (by_columns) { h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr; }
+  else if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
   // "pip_concurrent": the kernel goes to the handle's second stream and runs BESIDE the LSI kernel
   // of the same step on the main stream (both only read the maps and the tree): with an LSI query in
   // flight on its reduced grid (lsi_launch), on 5 blocks per CU; otherwise on the full grid.  Not
@@ -1478,7 +1579,13 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
                      n >= (uint64_t) 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top);  // (two 128-position groups per resident wave)
     h->last_tall[si] = two && tall;
     tic(h, RJ_T_PIP_WALK, st);
-    if (two) {
+    // a base map with a column index (isolated rings): the first pass reads the point's strip instead of walking the tree
+    const bool columns = w.bvh.strips.begin != nullptr && !h->stats_on;
+    h->last_columns = columns ? 1 : 0;
+    if (columns) {
+      w.group_lanes = 64;  // (one todo mask per 64 positions)
+      RJ_HIP(h, launch_pip_strip(st, w, walk_blocks, h->cus));
+    } else if (two) {
       if (aux && h->lsi_shared && !h->pip_share_set)
         walk_blocks = h->cus * pip_walk2_blocks_beside(w.bvh.top, h->lsi_share_blocks() / h->cus < 1 ? 1 : h->lsi_share_blocks() / h->cus);
       RJ_HIP(h, launch_pip_walk2(st, w, walk_blocks, h->cus));

@@ -79,6 +79,22 @@ struct DeviceMap {
   uint64_t np, ne, nc;
 };
 
+// The COLUMN index of an indexed map (round 4, maps of isolated rings): the domain cut into vertical strips of
+// 2^kStripShift quanta; per strip the sorted slots whose box touches it, ascending by box y0 (key = strip << 32 | y0).
+// An upward ray lives in ONE strip: the edges that can be above a point are found by a binary search for its height
+// and a short scan upwards -- O(log) per point wherever the point lies, where the box hierarchy opens every leaf
+// block over the column whose x-extent contains the point (20 per point on the lake-shaped stand-in, 19 of them with
+// nothing at that x).  The walk's job on such maps, with the walk's hand-over (k_pip_strip, rj_strip.hip).
+constexpr int kStripShift = 16;
+constexpr int kStrips = 1 << (31 - kStripShift);  // 32 768
+constexpr int kStripMaxSpan = 1024;               // strips one segment may touch (more: the index is not built)
+struct DeviceStrips {
+  const uint32_t* begin;  // [kStrips + 1] first entry of every strip
+  const uint64_t* key;    // [entries] strip << 32 | y0 of the slot's box, ascending
+  const uint32_t* slot;   // [entries] the sorted slot (box0 / seid / sface index)
+  const uint32_t* tall;   // [kStrips] largest box height (y1 - y0) among the strip's entries
+};
+
 struct DeviceBvh {
   const Seg* sseg;        // [n0p] segments in Morton order (padding = zero segments)
   const uint32_t* seid;   // [n0p] original eid of each sorted slot
@@ -91,6 +107,7 @@ struct DeviceBvh {
                           // (where the scan stops): the candidates of a point, without a search and without a stop test
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
   const uint32_t* sky;    // skyline, kSkyBuckets + 1 words (see kSkyShift); nullable
+  DeviceStrips strips;    // column index (begin == nullptr: none)
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
   // Behind the boxes of every level l (at lvl[l] + pad64(nlvl[l])) sits one 64-bit word per node:
   // bit k set = sibling k (same 64-entry group) lies HIGHER (box centre, ties by index) -- the
@@ -172,6 +189,17 @@ __device__ __forceinline__ int32_t bcast(int32_t v, int src_lane_uniform) {
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+// candidate slots a PIP walk keeps per query point (the todo record handed to k_pip_exact holds as many); a point
+// that needs more goes to the rest list
+#ifndef RJ_WALK_LIST
+#define RJ_WALK_LIST 6
+#endif
+constexpr int kWalkList = RJ_WALK_LIST;
+// the upward ray from the quantised point (qx, qy) can meet something: some segment over its x-bucket reaches its height
+// (see kSkyShift; `sky` null or not exhaustive: cannot tell)
+__device__ __forceinline__ bool ray_has_sky(const uint32_t* __restrict__ sky, int32_t qx, int32_t qy) {
+  return !sky || sky[(uint32_t) qx >> kSkyShift] > (uint32_t) qy;
 }
 // Closed-interval box overlap as ONE sign test: every difference below is non-negative exactly
 // when the corresponding inequality holds, and no difference can overflow (coordinates are 31-bit

@@ -491,12 +491,6 @@ __global__ __launch_bounds__(256) void k_sibling_order(const QBox* __restrict__ 
   }
 }
 
-// the upward ray from the quantised point (qx, qy) can meet something: some segment over its x-bucket reaches its height
-// (see kSkyShift; `sky` null or not exhaustive: cannot tell)
-__device__ __forceinline__ bool ray_has_sky(const uint32_t* __restrict__ sky, int32_t qx, int32_t qy) {
-  return !sky || sky[(uint32_t) qx >> kSkyShift] > (uint32_t) qy;
-}
-
 // number of lanes j with v[j] <= key, for v non-decreasing over the 64 lanes (lane j holds v[j]).
 // Two stages: 7 wave-uniform pivots (v at lanes 7, 15, ... 55; v_readlane -> SGPR, no latency chain)
 // pick the 8-lane bucket, then 3 dependent cross-lane probes + 1 finish inside it -- instead of 7
@@ -1579,10 +1573,6 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
 // Pruning is exactly k_pip's (certain hits bound a lane; a certain hit below the held one replaces it),
 // so whatever is settled here is what k_pip would have answered.
 // =============================================================================================
-#ifndef RJ_WALK_LIST
-#define RJ_WALK_LIST 6
-#endif
-constexpr int kWalkList = RJ_WALK_LIST;  // candidate slots per lane (the todo record holds as many); a lane that needs more goes to the rest list
 __host__ __device__ __forceinline__ int walk_stack_entries(int top) { return 64 + 63 * (top > 1 ? top - 1 : 0) + 3; }
 __host__ __device__ __forceinline__ size_t walk_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256; }
 

@@ -1,0 +1,117 @@
+"""The column index ("pip_columns": per vertical strip the slots whose box touches it, sorted by y0 -- rj_strip.hip) as
+the first pass of a PIP query against the oracle and against the tree walk: ring-shaped base maps (where it is built by
+default), a lattice base map (forced), adversarial integer lattices dense in ties (forced), caller-owned shuffled
+point arrays, both query-map ids, and the pair with an LSI query in flight."""
+import numpy as np
+import pytest
+
+from rayjoin_amd import _capi, maps, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _omap(oracle, m):
+    return oracle.Map(m.pts, m.row_index, m.left, m.right)
+
+
+def _pip(h, base, qpts_dev, n, closest, faces):
+    h.pip_query(base, 1 - base, qpts_dev, 0, n, closest, faces)
+    return closest.to_host(np.uint32)[:n].copy(), faces.to_host(np.int32)[:n].copy()
+
+
+@pytest.mark.parametrize("what", ["rings", "gaussian", "lattice"])
+def test_columns_equal_the_walk_and_the_oracle(oracle, what):
+    g0 = {"rings": lambda: synth.ring_map(6000, 70000, 3), "gaussian": lambda: synth.gaussian_polygons(20000, 4, polysize=0.01),
+          "lattice": lambda: synth.lattice_map(12, 60, 5)}[what]()
+    ctx = maps.Context([g0, synth.lattice_map(40, 25, 6)]).load()
+    m = ctx.maps
+    om = [_omap(oracle, m[0]), _omap(oracle, m[1])]
+    rng = np.random.default_rng(1)
+    h = _capi.Handle(0)
+    try:
+        for i in (0, 1):
+            h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
+        for base in (0, 1):
+            q = m[1 - base]
+            want = oracle.pip_grid(om[base], base, q.pts, 256)
+            shuffled = q.pts[rng.permutation(q.n_points)]
+            want_sh = oracle.pip_grid(om[base], base, np.ascontiguousarray(shuffled), 256)
+            closest, faces = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+            dsh = h.alloc(16 * q.n_points).from_host(shuffled)
+            got = {}
+            for columns in (1, 0, -1):
+                h.set_option("pip_columns", columns)
+                h.build_lbvh(base)
+                used = h.get_option("pip_columns_used%d" % base)
+                assert used == (1 if columns == 1 else 0 if columns == 0 else used)
+                if columns == -1 and base == 0:
+                    assert used == (0 if what == "lattice" else 1), what   # built where most chains are closed rings
+                e, f = _pip(h, base, None, q.n_points, closest, faces)
+                assert h.get_option("pip_last_columns") == used
+                assert np.array_equal(e, want), (what, base, columns)
+                assert np.array_equal(f, om[base].face_ids(want)), (what, base, columns)
+                e2, _ = _pip(h, base, dsh, q.n_points, closest, faces)
+                assert np.array_equal(e2, want_sh), (what, base, columns, "shuffled caller array")
+                got[columns] = e
+            assert np.array_equal(got[1], got[0])
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("seed,span,extreme", [(1, 4, False), (3, 6, True)])
+def test_columns_on_adversarial_integer_lattices(oracle, seed, span, extreme):
+    a = synth.adversarial_segments(700, span, seed, extreme)
+    b = synth.adversarial_segments(900, span, seed + 50, extreme)
+    ma, mb = maps.ScaledMap.from_segments(0, a), maps.ScaledMap.from_segments(1, b)
+    o = [oracle.Map(a), oracle.Map(b)]
+    rng = np.random.default_rng(seed)
+    pts = rng.integers(-span - 1, span + 2, size=(3000, 2))
+    if extreme:
+        pts = np.clip(a[rng.integers(0, len(a), 3000)] + rng.integers(-3, 4, size=(3000, 2)), -(1 << 46), (1 << 46) - 1)
+    pts = np.ascontiguousarray(pts, dtype=np.int64)
+    h = _capi.Handle(0)
+    try:
+        h.upload_map(0, ma.pts, ma.row_index, ma.left, ma.right)
+        h.upload_map(1, mb.pts, mb.row_index, mb.left, mb.right)
+        h.set_option("pip_columns", 1)
+        d = h.alloc(16 * len(pts)).from_host(pts)
+        closest = h.alloc(4 * len(pts))
+        for base in (0, 1):
+            h.build_lbvh(base)
+            assert h.get_option("pip_columns_used%d" % base) == 1
+            h.pip_query(base, 1 - base, d, 0, len(pts), closest, None)
+            assert np.array_equal(closest.to_host(np.uint32), oracle.pip_brute(o[base], 1 - base, pts)), (seed, base)
+    finally:
+        h.close()
+
+
+def test_columns_beside_an_lsi_query(oracle):
+    ctx = maps.Context([synth.ring_map(5000, 60000, 8), synth.lattice_map(40, 25, 9)]).load()
+    b, q = ctx.maps
+    m0, m1 = _omap(oracle, b), _omap(oracle, q)
+    want_pairs = oracle.lsi_grid(m0, m1, 256)["eid"]
+    want_e = oracle.pip_grid(m0, 0, q.pts, 256)
+    h = _capi.Handle(0)
+    try:
+        h.upload_map(0, b.pts, b.row_index, b.left, b.right)
+        h.upload_map(1, q.pts, q.row_index, q.left, q.right)
+        h.build_lbvh(0)
+        assert h.get_option("pip_columns_used0") == 1
+        cap = 4 * len(want_pairs) + 64
+        pairs, xs = h.alloc(8 * cap), h.alloc(48 * cap)
+        closest, faces = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+        for conc in (1, 2, 0):
+            h.set_option("pip_concurrent", conc)
+            for rep in range(6):
+                closest.from_host(np.full(q.n_points, 0xDEADBEEF, dtype=np.uint32))
+                h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs)
+                h.pip_query(0, 1, None, 0, q.n_points, closest, faces, sync=False)
+                h.lsi_points_async(pairs, cap, xs)
+                n = h.lsi_query_finish(cap)
+                h.sync()
+                assert n == len(want_pairs)
+                assert np.array_equal(oracle.sort_pairs(pairs.to_host(np.uint32, 2 * n).reshape(-1, 2).copy()), want_pairs)
+                assert np.array_equal(closest.to_host(np.uint32), want_e), (conc, rep)
+                assert np.array_equal(faces.to_host(np.int32), m0.face_ids(want_e)), (conc, rep)
+    finally:
+        h.close()
