@@ -374,6 +374,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     schedule = h.get_option("pip_schedule")  # (read now: a later index build starts the decision again)
     state["walk_points"] = h.get_option("pip_last_walk_points")  # (which kernels the timed steps ran: one or two queries per lane)
     state["lsi_segments"] = h.get_option("lsi_last_segments")
+    state["columns"] = h.get_option("pip_last_columns")
     share = (h.get_option("lsi_share_blocks"), h.get_option("pip_share_blocks"))
     pip_rest = h.get_option("pip_rest_aux" if schedule in (1, 2) else "pip_rest") if h.get_option("pip_walk") else None
     closest = state["closest"]
@@ -462,7 +463,9 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                 traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_* (counter passes: each kernel alone on its full grid)" % doc.get("tag")
             else:
                 prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
-        pip_kernel = ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk") if state["two_pass"] else "k_pip"
+        # (a base map of isolated rings has a column index: the first pass reads the point's strip instead of walking the tree)
+        walk_name = "k_pip_strip" if state.get("columns") else ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk")
+        pip_kernel = walk_name if state["two_pass"] else "k_pip"
         lsi_kernel = "k_lsi2" if state["lsi_segments"] == 2 else "k_lsi"
         # the PIP query's dominant kernel: its own HIP-event time in the timed steps (the three PIP kernels together: query_ms)
         pip_dom_ms = walk_k if walk_k else pip_k
@@ -538,7 +541,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                                            -1: "k_lsi, then the PIP kernels (re-ordered query sets are never paired)" if never_paired
                                                else "undecided (fewer than 5 paired steps)"}[schedule],
                        "schedule_settled_before_timing": bool(settled),
-                       "pip_passes": ("%s + k_pip_exact (its first blocks locate the %s points whose candidate list overflowed)" % ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk", pip_rest)) if state["two_pass"]
+                       "pip_passes": ("%s + k_pip_exact (its first blocks locate the %s points whose candidate list overflowed)" % (walk_name, pip_rest)) if state["two_pass"]
                                      else "k_pip alone" + (" (the walk left %s lists to it: auto dropped the first pass)" % pip_rest if h.get_option("pip_walk") else "")},
             "lsi_ms": round(t_lsi_wall * 1e3, 4), "pip_ms": round(t_pip_wall * 1e3, 4),
             "lsi_msegs_per_s": round(n_s_loc * world / max(t_lsi_wall, 1e-9) / 1e6, 2) if world == 1 else None,
@@ -548,6 +551,9 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             "build_index_runs_ms": round(build_runs_ms, 3), "rebuild_index_ms": round(build_ms, 3),
             "pip_caller_array": caller,
             "index_leaves": "polyline runs" if h.get_option("leaf_order_used0") == 1 else "Hilbert neighbours",
+            "index_slots_per_segment": round(h.get_option("leaf_slots0") / max(1, n_r), 3),
+            "index_extras": {"skyline": bool(h.get_option("skyline_used0")), "pip_columns": bool(h.get_option("pip_columns_used0")),
+                             "closed_chains": h.get_option("closed_chains0")},
             "host_ms": {"generate": round(t_gen * 1e3, 1), "upload_and_segment_build": round(t_upload * 1e3, 1)},
             "roofline": roof[dom], "roofline_other": roof["pip" if dom == "lsi" else "lsi"],
             # the whole step against the same roofline: all algorithmic bytes of the step over the step's time
@@ -607,7 +613,7 @@ def main():
             torch.cuda.empty_cache()
             line = run_workload(args, env, b, q, max(5, min(args.steps, 10)), max(5, args.warmup), False, with_cpu)
             sec.append({k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_slowest_step", "config", "intersections",
-                                             "build_index_ms", "build_index_wall_ms", "rebuild_index_ms", "index_leaves", "lsi_points_ms", "roofline", "roofline_other", "roofline_step",
+                                             "build_index_ms", "build_index_wall_ms", "rebuild_index_ms", "index_leaves", "index_slots_per_segment", "index_extras", "pip_caller_array", "ms_per_step_pipelined", "lsi_points_ms", "roofline", "roofline_other", "roofline_step",
                                              "cpu_baseline") if k in line})
         out["secondary"] = sec
     if rank == 0:

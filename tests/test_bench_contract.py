@@ -22,7 +22,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # round 3: the dominant kernel is the PIP walk; the line says what the number is (algorithmic bytes vs moved bytes)
-    assert r["kernel"] in ("k_pip_walk", "k_pip_walk2", "k_lsi", "k_lsi2") and "query_ms" in (r if r["kernel"].startswith("k_pip_walk") else d["roofline_other"])
+    assert r["kernel"] in ("k_pip_walk", "k_pip_walk2", "k_pip_strip", "k_lsi", "k_lsi2") and "query_ms" in (r if r["kernel"].startswith("k_pip_") else d["roofline_other"])
     if r.get("traffic"):
         assert 0 < r["traffic_frac"] < 1 and r["limiter"] in ("valu-issue", "dependent-load latency") and 0 < r["limiter_frac"] <= 1
     c = d["cpu_baseline"]

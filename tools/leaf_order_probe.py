@@ -8,7 +8,7 @@ from rayjoin_amd import _capi, maps, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--base", default="USCounty"); ap.add_argument("--query", default="BlockGroup")
 ap.add_argument("--scale", type=float, default=1.0); ap.add_argument("--reps", type=int, default=4)
-ap.add_argument("--variants", default="0:0,1:0", help="leaf_order:debug_pack_solo[:debug_run_cap[:debug_pack_spread]] , ...  (0 = the default of each)")
+ap.add_argument("--variants", default="0:0,1:0", help="leaf_order:pack_solo[:run_cap[:pack_spread[:pip_columns]]] , ...  (0 = the default of each; pip_columns: 2 = auto, 0 never, 1 always)")
 a = ap.parse_args()
 ctx = maps.Context([synth.standin(a.base, a.scale), synth.standin(a.query, a.scale)]).load()
 b, q = ctx.maps
@@ -22,6 +22,7 @@ first = None
 for var in a.variants.split(","):
     f = [int(x) for x in var.split(":")]
     order, solo, rcap, spread = f[0], (f[1] if len(f) > 1 else 0), (f[2] if len(f) > 2 else 0), (f[3] if len(f) > 3 else 0)
+    h.set_option("pip_columns", -1 if len(f) <= 4 or f[4] == 2 else f[4])
     if rcap != h.get_debug_option("run_cap"):  # (the runs are cut once per uploaded map: cut them again)
         h.upload_map(0, b.pts, b.row_index, b.left, b.right)
     h.set_debug_option("run_cap", rcap)
@@ -31,7 +32,8 @@ for var in a.variants.split(","):
     h.build_lbvh(0); first_ms = h.last_ms(_capi.RJ_T_BUILD); h.build_lbvh(0)
     order = var
     out = {"pair": "%s x %s" % (a.base, a.query), "variant": var, "first_build_ms": round(first_ms, 3), "build_ms": round(h.last_ms(_capi.RJ_T_BUILD), 3),
-           "slots_per_segment": round(h.get_option("leaf_slots0") / b.n_edges, 3), "used": h.get_option("leaf_order_used0")}
+           "slots_per_segment": round(h.get_option("leaf_slots0") / b.n_edges, 3), "used": h.get_option("leaf_order_used0"),
+           "skyline": h.get_option("skyline_used0"), "columns": h.get_option("pip_columns_used0")}
     l, p, w = [], [], []
     for _ in range(a.reps):
         n = h.lsi_query(0, 1, 0, q.n_edges, cap, pairs); l.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))

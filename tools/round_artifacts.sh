@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $R
 tools/profile_run.sh $TAG > gpurun_out/${TAG}_run.log 2>&1
 echo "profile_run done"
-for p in "USCounty Zipcode" "USCounty NestedBlockGroup" "WaterBodies BlockGroup" "LakesNA ParksNA" "Gaussian5M Gaussian1M"; do
+for p in "USCounty Zipcode" "USCounty NestedBlockGroup" "WaterBodies BlockGroup" "LakesNA ParksNA" "Gaussian5M Gaussian1M" "WaterBodiesLike BlockGroup" "LakesLike ParksLike" "BlockGroup WaterBodiesLike"; do
   set -- $p
   timeout -k 10 300 python3 bench.py --base $1 --query $2 --check --steps 20 --warmup 5 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench_$1_$2.json
   echo "bench $1 $2 done"
@@ -19,11 +19,12 @@ timeout -k 10 200 python3 bench.py --base WaterBodies --query BlockGroup --emula
 timeout -k 10 200 python3 bench.py --serial-kernels --no-secondary --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench_serial.json
 echo "shards done"
 : > gpurun_out/${TAG}_leaf_order.txt
-for p in "USCounty BlockGroup" "USCounty Zipcode" "USCounty NestedBlockGroup" "WaterBodies BlockGroup" "LakesNA ParksNA" "Gaussian5M Gaussian1M"; do
+for p in "USCounty BlockGroup" "USCounty Zipcode" "USCounty NestedBlockGroup" "WaterBodies BlockGroup" "LakesNA ParksNA" "Gaussian5M Gaussian1M" "WaterBodiesLike BlockGroup" "LakesLike ParksLike"; do
   set -- $p
-  timeout -k 10 300 python3 tools/leaf_order_probe.py --base $1 --query $2 --reps 3 2>/dev/null | tail -3 >> gpurun_out/${TAG}_leaf_order.txt
+  timeout -k 10 400 python3 tools/leaf_order_probe.py --base $1 --query $2 --reps 3 2>/dev/null | tail -3 >> gpurun_out/${TAG}_leaf_order.txt
 done
 echo "leaf order done"
 timeout -k 10 200 python3 tools/schedule_probe.py --steps 8 2>/dev/null | grep "^{" > gpurun_out/${TAG}_schedule_probe.txt
-timeout -k 10 200 python3 tools/build_probe.py 2>/dev/null | tail -12 > gpurun_out/${TAG}_build_probe.txt
+timeout -k 10 400 python3 tools/build_probe.py --maps USCounty,BlockGroup,WaterBodies,LakesNA,WaterBodiesLike,LakesLike 2>/dev/null | tail -12 > gpurun_out/${TAG}_build_probe.txt
+timeout -k 10 300 python3 tools/ring_stats_probe.py 2>/dev/null > gpurun_out/${TAG}_ring_stats.txt
 echo "all done"
