@@ -84,7 +84,7 @@ def kernel_source_hash():
     (profiles/traffic.json) carry it, and bench.py only quotes them for the sources they measured."""
     import hashlib
     hsh = hashlib.sha256()
-    for name in ("rj_kernels.hip", "rj_kernels.h", "rj_device.h", "rj_predicates.h"):
+    for name in ("rj_kernels.hip", "rj_kernels.h", "rj_device.h", "rj_predicates.h", "rj_strip.hip"):
         with open(os.path.join(HERE, "csrc", name), "rb") as f:
             hsh.update(f.read())
     return hsh.hexdigest()[:16]

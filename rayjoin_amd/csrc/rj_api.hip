@@ -59,8 +59,8 @@ struct BvhState {
   bool use_sky = false;     // ... filled and used (maps of isolated rings)
   // the column index (rj_device.h DeviceStrips; maps of isolated rings): what the PIP query's first pass runs on instead
   // of the tree
-  uint32_t *strip_begin = nullptr, *strip_slot = nullptr, *strip_tall = nullptr;
-  uint64_t* strip_key = nullptr;
+  uint32_t *strip_ytab = nullptr, *strip_slot = nullptr, *strip_tall = nullptr;
+  QBox* strip_box = nullptr;
   uint64_t strip_entries = 0, strip_cap = 0;
   bool strips_built = false;
   QBox* lvl[kMaxLevels] = {nullptr};  // boxes of level l, then one sibling-order word per node (rj_device.h)
@@ -312,7 +312,7 @@ void free_grid(GridState& g) {
 
 void free_bvh(BvhState& b) {
   (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
-  (void) hipFree(b.strip_begin); (void) hipFree(b.strip_slot); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_key);
+  (void) hipFree(b.strip_ytab); (void) hipFree(b.strip_slot); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_box);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
@@ -325,8 +325,8 @@ DeviceBvh bvh_view(const BvhState& b) {
     d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
   }
   d.top = b.top; d.n0 = b.n0;
-  d.strips.begin = b.strips_built ? b.strip_begin : nullptr;
-  d.strips.key = b.strip_key; d.strips.slot = b.strip_slot; d.strips.tall = b.strip_tall;
+  d.strips.ytab = b.strips_built ? b.strip_ytab : nullptr;
+  d.strips.ebox = b.strip_box; d.strips.eslot = b.strip_slot; d.strips.tall = b.strip_tall;
   return d;
 }
 
@@ -890,8 +890,8 @@ static int build_strips(rj_handle h, BvhState& b) {
   const uint32_t total = (uint32_t) h->h_pinned[30], bad = (uint32_t) (h->h_pinned[30] >> 32);
   if (bad || total == 0) return RJ_OK;  // (a segment spanning more than kStripMaxSpan strips: the tree alone serves this map)
   size_t sort_bytes = 0;
-  RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, b.n0p, total, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
-  const size_t need = 2 * cnt_bytes + 256 + up(8 * (size_t) total) + up(4 * (size_t) total) + up(sort_bytes);
+  RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, b.n0p, total, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
+  const size_t need = 2 * cnt_bytes + 256 + 2 * up(8 * (size_t) total) + up(4 * (size_t) total) + up(sort_bytes);
   if (need > h->strip_scratch_bytes) {
     // (the counts live in the scratch block that is about to move: count again into the new one -- first build of a
     //  larger map only)
@@ -902,23 +902,24 @@ static int build_strips(rj_handle h, BvhState& b) {
     RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, cnt, offs, temp, tb, flag));
   }
   uint64_t* key_tmp = (uint64_t*) (h->strip_scratch + 2 * cnt_bytes + 256);
-  uint32_t* slot_tmp = (uint32_t*) ((char*) key_tmp + up(8 * (size_t) total));
+  uint64_t* key = (uint64_t*) ((char*) key_tmp + up(8 * (size_t) total));
+  uint32_t* slot_tmp = (uint32_t*) ((char*) key + up(8 * (size_t) total));
   temp = (char*) slot_tmp + up(4 * (size_t) total);
   if (b.strip_cap < total) {
-    (void) hipFree(b.strip_slot); (void) hipFree(b.strip_key);
-    b.strip_slot = nullptr; b.strip_key = nullptr; b.strip_cap = 0;
+    (void) hipFree(b.strip_slot); (void) hipFree(b.strip_box);
+    b.strip_slot = nullptr; b.strip_box = nullptr; b.strip_cap = 0;
     const uint64_t cap = (uint64_t) total + total / 16;
-    if (int r = dev_alloc(h, &b.strip_key, cap)) return r;
+    if (int r = dev_alloc(h, &b.strip_box, cap)) return r;
     if (int r = dev_alloc(h, &b.strip_slot, cap)) return r;
     b.strip_cap = cap;
   }
   if (!b.strip_tall) {
     if (int r = dev_alloc(h, &b.strip_tall, (uint64_t) kStrips)) return r;
-    if (int r = dev_alloc(h, &b.strip_begin, (uint64_t) kStrips + 1)) return r;
+    if (int r = dev_alloc(h, &b.strip_ytab, ((uint64_t) kStrips << kStripYBits) + 1)) return r;
   }
   tb = sort_bytes;
-  RJ_HIP(h, launch_strip_fill(h->stream, b.box0, cnt, offs, b.n0p, total, b.strip_key, b.strip_slot, key_tmp, slot_tmp, b.strip_tall,
-                              b.strip_begin, temp, tb));
+  RJ_HIP(h, launch_strip_fill(h->stream, b.box0, cnt, offs, b.n0p, total, key, b.strip_slot, key_tmp, slot_tmp, b.strip_tall,
+                              b.strip_ytab, b.strip_box, temp, tb));
   b.strip_entries = total;
   b.strips_built = true;
   return RJ_OK;
@@ -1580,7 +1581,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     h->last_tall[si] = two && tall;
     tic(h, RJ_T_PIP_WALK, st);
     // a base map with a column index (isolated rings): the first pass reads the point's strip instead of walking the tree
-    const bool columns = w.bvh.strips.begin != nullptr && !h->stats_on;
+    const bool columns = w.bvh.strips.ytab != nullptr && !h->stats_on;
     h->last_columns = columns ? 1 : 0;
     if (columns) {
       w.group_lanes = 64;  // (one todo mask per 64 positions)

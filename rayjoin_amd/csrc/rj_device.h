@@ -80,18 +80,21 @@ struct DeviceMap {
 };
 
 // The COLUMN index of an indexed map (round 4, maps of isolated rings): the domain cut into vertical strips of
-// 2^kStripShift quanta; per strip the sorted slots whose box touches it, ascending by box y0 (key = strip << 32 | y0).
-// An upward ray lives in ONE strip: the edges that can be above a point are found by a binary search for its height
-// and a short scan upwards -- O(log) per point wherever the point lies, where the box hierarchy opens every leaf
-// block over the column whose x-extent contains the point (20 per point on the lake-shaped stand-in, 19 of them with
-// nothing at that x).  The walk's job on such maps, with the walk's hand-over (k_pip_strip, rj_strip.hip).
+// 2^kStripShift quanta; per strip the boxes of the sorted slots that touch it, ascending by y0, and a table of where
+// every one of 256 height buckets starts in that list.  An upward ray lives in ONE strip: one table read finds the
+// entries at its height, a short scan upwards finds the edges above it -- O(1) per point wherever the point lies, where
+// the box hierarchy opens every leaf block over the column whose x-extent contains the point (20 per point on the
+// lake-shaped stand-in, 19 of them with nothing at that x).  The walk's job on such maps, with the walk's hand-over
+// (k_pip_strip, rj_strip.hip).
 constexpr int kStripShift = 16;
 constexpr int kStrips = 1 << (31 - kStripShift);  // 32 768
+constexpr int kStripYBits = 8;                    // height buckets per strip: 256 of 2^23 quanta
+constexpr int kStripYShift = 31 - kStripYBits;
 constexpr int kStripMaxSpan = 1024;               // strips one segment may touch (more: the index is not built)
 struct DeviceStrips {
-  const uint32_t* begin;  // [kStrips + 1] first entry of every strip
-  const uint64_t* key;    // [entries] strip << 32 | y0 of the slot's box, ascending
-  const uint32_t* slot;   // [entries] the sorted slot (box0 / seid / sface index)
+  const uint32_t* ytab;   // [kStrips * 256 + 1] first entry at or above (strip, height bucket); nullptr: no index
+  const QBox* ebox;       // [entries] the slot's box, entries ascending by (strip, y0)
+  const uint32_t* eslot;  // [entries] the sorted slot (seid / sface index)
   const uint32_t* tall;   // [kStrips] largest box height (y1 - y0) among the strip's entries
 };
 
@@ -107,7 +110,7 @@ struct DeviceBvh {
                           // (where the scan stops): the candidates of a point, without a search and without a stop test
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
   const uint32_t* sky;    // skyline, kSkyBuckets + 1 words (see kSkyShift); nullable
-  DeviceStrips strips;    // column index (begin == nullptr: none)
+  DeviceStrips strips;    // column index (ytab == nullptr: none)
   const QBox* lvl[kMaxLevels];  // lvl[l] for l = 1..top, each padded to a multiple of 64
   // Behind the boxes of every level l (at lvl[l] + pad64(nlvl[l])) sits one 64-bit word per node:
   // bit k set = sibling k (same 64-entry group) lies HIGHER (box centre, ties by index) -- the

@@ -3,14 +3,16 @@
 // Built for maps of isolated rings, where the box hierarchy is at its worst for upward rays: a leaf block of a few
 // rings is mostly gaps in x, and a point opens every block over its column whose x-extent contains it until one
 // holds an edge at its x -- measured on the lake-shaped stand-in: 20 leaf blocks opened per point, one segment box
-// tested.  Here a point reads its strip's list: a binary search for its height, then the entries upwards until a
-// certain hit bounds the answer.  The pass is k_pip_walk's in every other respect -- integer tests only, the same
+// tested.  Here a point reads its strip's list: one table read for its height (256 buckets per strip), then the
+// entries' boxes upwards -- consecutive 16-byte reads -- until a certain hit bounds the answer.  (First version: a
+// binary search over 8-byte keys, then key -> slot -> box per entry: 4.9 ms for the 29.7 M lattice vertices.)  The pass is k_pip_walk's in every other respect -- integer tests only, the same
 // certain-hit pruning, the same hand-over (settled points written, candidate lists in `todo`, overflowed lists in
 // `rest`) -- so k_pip_exact follows it unchanged and the results are the walk's (tests/test_gpu_strip.py).
 #include <hip/hip_runtime.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/reverse_iterator.hpp>
 
 #include "rj_kernels.h"
 
@@ -55,15 +57,21 @@ __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box
     }
   }
 }
-// begin[s] = first entry whose strip is >= s (the keys are sorted)
-__global__ __launch_bounds__(256) void k_strip_begin(const uint64_t* __restrict__ key, uint64_t n, uint32_t* __restrict__ begin) {
-  RJ_GRID_STRIDE(s, (uint64_t) kStrips + 1) {
-    uint64_t lo = 0, hi = n;
-    while (lo < hi) {
-      const uint64_t mid = (lo + hi) >> 1;
-      if ((uint32_t) (key[mid] >> 32) < (uint32_t) s) lo = mid + 1; else hi = mid;
-    }
-    begin[s] = (uint32_t) lo;
+// the sorted entries: their boxes beside them, and where every (strip, height bucket) starts.  The first entry of a
+// bucket writes its index at the bucket (the table is pre-filled with "no entry": 0xFFFFFFFF, the slot behind the last
+// bucket with the entry count); a suffix minimum over the table then gives every empty bucket the first entry behind
+// it.  (Filling the gaps from the entries themselves left one thread writing millions of buckets where the map is a
+// small cluster in a large domain: +7 ms on the gaussian polygons.)
+__device__ __forceinline__ uint32_t strip_bucket(uint64_t key) {
+  return ((uint32_t) (key >> 32) << kStripYBits) | ((uint32_t) key >> kStripYShift);
+}
+__global__ __launch_bounds__(256) void k_strip_finish(const uint64_t* __restrict__ key, const uint32_t* __restrict__ slot, uint64_t n,
+                                                      const QBox* __restrict__ box0, QBox* __restrict__ ebox, uint32_t* __restrict__ ytab) {
+  RJ_GRID_STRIDE(j, n) {
+    ebox[j] = box0[slot[j]];
+    const uint32_t g = strip_bucket(key[j]);
+    if (j == 0 || strip_bucket(key[j - 1]) != g) ytab[g] = (uint32_t) j;
+    if (j == n - 1) ytab[(uint32_t) kStrips << kStripYBits] = (uint32_t) n;
   }
 }
 
@@ -98,38 +106,29 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     const uint32_t cand_base = (uint32_t) lane;
     uint32_t cand_at = cand_base;
     int32_t sure_y0 = INT32_MIN;
-    // the strip's entries from the first that can still reach up to the point: y0 >= qy - 1 - (tallest box of the strip)
+    // the strip's entries from the height bucket of the lowest y0 that can still reach up to the point
+    // (y0 >= qy - 1 - the tallest box of the strip); what lies below the point inside that bucket fails the test
     uint32_t j = 0, jend = 0;
     if (live) {
       const uint32_t s = (uint32_t) qx >> kStripShift;
-      uint32_t lo = S.begin[s];
-      const uint32_t hi = S.begin[s + 1];
-      jend = hi;
       const int64_t from = (int64_t) qym1 - (int64_t) S.tall[s];
       const uint32_t want = from > 0 ? (uint32_t) from : 0u;
-      uint32_t n = hi - lo;  // lower bound of `want` among the low words of key[lo, hi)
-      while (n) {
-        const uint32_t half = n >> 1;
-        const bool below = (uint32_t) S.key[lo + half] < want;
-        lo = below ? lo + half + 1 : lo;
-        n = below ? n - half - 1 : half;
-      }
-      j = lo;
+      j = S.ytab[(s << kStripYBits) | (want >> kStripYShift)];
+      jend = S.ytab[(s + 1) << kStripYBits];
     }
     while (j < jend) {
-      const int32_t sy0 = (int32_t) (uint32_t) S.key[j];
-      if (sy0 > qbest) break;  // everything further starts above the bound
-      const uint32_t slot = S.slot[j];
-      const QBox b = T.box0[slot];
+      const QBox b = S.ebox[j];
+      if (b.y0 > qbest) break;  // everything further starts above the bound
       if (((qx - b.x0) | (b.x1 - qx) | (b.y1 - qym1)) >= 0) {
         // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
         // ends below the start of the one certain hit held so far replaces it
-        const bool certain = b.x0 < qx && qx < b.x1 && sy0 > qy;
+        const uint32_t slot = S.eslot[j];
+        const bool certain = b.x0 < qx && qx < b.x1 && b.y0 > qy;
         const bool replace = certain && b.y1 < sure_y0;
         const bool first = cand_at == cand_base;
         const bool over = !replace && cand_at == cand_base + kWalkList * 64;
         cand[(replace || over) ? cand_base : cand_at] = slot;
-        sure_y0 = (replace || (first && certain)) ? sy0 : INT32_MIN;
+        sure_y0 = (replace || (first && certain)) ? b.y0 : INT32_MIN;
         cand_at += replace ? 0u : 64u;
         const int32_t top = certain ? b.y1 + 1 : 0x7FFFFFFF;
         qbest = over ? -1 : (top < qbest ? top : qbest);
@@ -184,19 +183,36 @@ hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* 
   hipLaunchKernelGGL(k_strip_count, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, seid, n0p, cnt, flag);
   return rocprim::exclusive_scan(temp, temp_bytes, cnt, offs, 0u, (size_t) n0p + 1, rocprim::plus<uint32_t>(), st);  // offs[n0p] = the total
 }
-// pass 2: the entries, sorted by (strip, y0); key_tmp / slot_tmp: sort buffers of the same size; tall[kStrips] zeroed here
+// pass 2: the entries, sorted by (strip, y0), with their boxes and the height-bucket table; key / key_tmp / slot_tmp:
+// temporaries of `entries` elements; tall[kStrips] zeroed here
 hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* cnt, const uint32_t* offs, uint64_t n0p, uint64_t entries,
-                             uint64_t* key, uint32_t* slot, uint64_t* key_tmp, uint32_t* slot_tmp, uint32_t* tall, uint32_t* begin,
-                             void* temp, size_t& temp_bytes) {
+                             uint64_t* key, uint32_t* eslot, uint64_t* key_tmp, uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab,
+                             QBox* ebox, void* temp, size_t& temp_bytes) {
   const unsigned bits = 32 + (31 - kStripShift);
-  if (!temp) return rocprim::radix_sort_pairs(nullptr, temp_bytes, (const uint64_t*) nullptr, (uint64_t*) nullptr, (const uint32_t*) nullptr,
-                                              (uint32_t*) nullptr, (size_t) entries, 0, bits, st);
+  if (!temp) {
+    size_t a = 0, b = 0;
+    hipError_t q = rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*) nullptr, (uint64_t*) nullptr, (const uint32_t*) nullptr,
+                                             (uint32_t*) nullptr, (size_t) entries, 0, bits, st);
+    if (q != hipSuccess) return q;
+    uint32_t* z = nullptr;
+    auto rz = rocprim::make_reverse_iterator(z);
+    q = rocprim::inclusive_scan(nullptr, b, rz, rz, ((size_t) kStrips << kStripYBits) + 1, rocprim::minimum<uint32_t>(), st);
+    temp_bytes = a > b ? a : b;
+    return q;
+  }
   hipError_t e = hipMemsetAsync(tall, 0, (size_t) kStrips * 4, st);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_strip_emit, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, cnt, offs, n0p, key_tmp, slot_tmp, tall);
-  if ((e = rocprim::radix_sort_pairs(temp, temp_bytes, key_tmp, key, slot_tmp, slot, (size_t) entries, 0, bits, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_begin, dim3(blocks_for(kStrips + 1)), dim3(256), 0, st, key, entries, begin);
-  return hipGetLastError();
+  if ((e = rocprim::radix_sort_pairs(temp, temp_bytes, key_tmp, key, slot_tmp, eslot, (size_t) entries, 0, bits, st)) != hipSuccess) return e;
+  const size_t nt = ((size_t) kStrips << kStripYBits) + 1;
+  if ((e = hipMemsetAsync(ytab, 0xFF, nt * 4, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_strip_finish, dim3(blocks_for(entries)), dim3(256), 0, st, key, eslot, entries, box0, ebox, ytab);
+  // suffix minimum, in place (the sort's temporary storage is free again and larger than a scan's)
+  size_t need = 0;
+  auto rb = rocprim::make_reverse_iterator(ytab + nt);
+  if ((e = rocprim::inclusive_scan(nullptr, need, rb, rb, nt, rocprim::minimum<uint32_t>(), st)) != hipSuccess) return e;
+  if (need > temp_bytes) return hipErrorInvalidValue;
+  return rocprim::inclusive_scan(temp, need, rb, rb, nt, rocprim::minimum<uint32_t>(), st);
 }
 
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus) {
