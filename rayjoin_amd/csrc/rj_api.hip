@@ -942,10 +942,15 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   // first time an index of this map wants them and kept (a later rebuild only sorts the runs).
   if (h->leaf_order == 1 && m.ne && m.nc < (1ull << 30) && !m.runs_cut) {
     MapState& mm = h->map[base_map_id];
-    // How long a run may be: a full leaf.  (Round 3 cut maps of short chains into runs of 32 -- fat, steep strips whose
-    // edges all overlap in x made the in-leaf scans of 64-edge runs slower on the WaterBodies lattice; with the leaf
-    // scans on the x-bucket table that no longer shows: k_lsi 1.27 ms with 64 against 1.31, the index half the size.)
-    uint32_t cap_edges = 64;
+    // How long a run may be.  A full leaf (64 edges) is right where chains are long: the strip is a piece of one smooth
+    // line.  A polyline stitched from many SHORT chains wiggles through a junction every few edges, its strip is fat,
+    // and where it runs steeply all of its edges overlap in x: the in-leaf scans test every slot and the PIP walk's
+    // candidate lists overflow.  Measured again in round 4 on the WaterBodies lattice (10-edge chains), query alone:
+    // runs of 32, one per leaf (2.12 slots per segment) k_lsi 1.11 ms, PIP 1.94; runs of 64 (1.12 slots) 1.27 / 2.39 and
+    // the walk dropped for its overflowed lists in the step (3.64 ms against 2.7); runs of 32 sharing leaves in pairs
+    // (1.46 slots) 1.31 / 2.37.  So: the cap follows the mean chain length, and a run that fills three quarters of its
+    // cap keeps its leaf (k_pack_runs) -- twice the index there, the faster one.
+    uint32_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
     if (h->debug_run_cap) cap_edges = (uint32_t) h->debug_run_cap;
     uint64_t max_pieces = 0, max_runs = 0;
     stitch_output_bounds(mm.nc, mm.ne, cap_edges, &max_pieces, &max_runs);
@@ -990,9 +995,9 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if (!rc) rc = dev_alloc(h, &mm.pack_tmp, 2 * (nchunks + 1));
       if (rc) return rc;
     }
-    // a run longer than this keeps its leaf to itself (a nearly full strip of one polyline gains little from a tenant and
-    // its box would have to be computed); a shared leaf may be `spread` times as large as what it holds
-    const uint32_t solo_above = h->debug_pack_solo ? (uint32_t) h->debug_pack_solo : 48;
+    // a run longer than three quarters of the cap keeps its leaf to itself (a nearly full strip of one polyline gains
+    // little from a tenant and its box would have to be computed); a shared leaf may be `spread` times as large as what it holds
+    const uint32_t solo_above = h->debug_pack_solo ? (uint32_t) h->debug_pack_solo : (mm.run_cap ? mm.run_cap : 64u) * 3 / 4;
     // (measured on the ring-shaped pairs, PIP query alone: 4 / 8 / 16 -> lake-shaped base 40.2 / 41.6 / 41.8 ms, lakes x
     //  parks 18.7 / 19.7 / 24.2, gaussian polygons 2.46 / 2.25 / 2.18: 8)
     const uint32_t spread = h->debug_pack_spread ? (uint32_t) h->debug_pack_spread : 8;

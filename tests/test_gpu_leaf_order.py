@@ -92,18 +92,19 @@ def test_short_rings_share_leaves(oracle):
         try:
             for i in (0, 1):
                 h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
-            # (sharing whatever the gaps -- nearly full leaves; the default rule -- a shared leaf at most 4 x as large as
+            # (sharing whatever the gaps, runs of up to 48 edges -- nearly full leaves; the same with the default run rule;
+            #  the default rule -- a shared leaf at most 4 x as large as
             #  what it holds: full where the rings are dense, one ring per leaf or the Hilbert fall-back where they are
             #  far apart; sharing forbidden -- the fall-back)
-            for solo, spread, used in ((0, 1000, 1), (0, 0, None), (1, 0, 0)):
+            for solo, spread, used, bound in ((48, 1000, 1, 1.3), (0, 1000, 1, 1.7), (0, 0, None, None), (1, 0, 0, None)):
                 h.set_option("leaf_order", 1)
                 h.set_debug_option("pack_solo", solo)
                 h.set_debug_option("pack_spread", spread)
                 pairs, closest, face = _run(h, 0, m[1], 8 * len(want_pairs) + 1024)
                 if used is not None:
                     assert h.get_option("leaf_order_used0") == used, (what, solo, spread)
-                if used:
-                    assert h.get_option("leaf_slots0") <= 1.3 * m[0].n_edges + 64, (what, h.get_option("leaf_slots0"), m[0].n_edges)
+                if bound:   # (the default keeps a run of more than 3/4 of the cap alone: the heavy tail of the rings' sizes costs slots)
+                    assert h.get_option("leaf_slots0") <= bound * m[0].n_edges + 64, (what, solo, h.get_option("leaf_slots0"), m[0].n_edges)
                 assert np.array_equal(pairs, want_pairs), (what, solo, spread)
                 assert np.array_equal(closest, want_e), (what, solo, spread)
                 assert np.array_equal(face, om[0].face_ids(want_e)), (what, solo, spread)

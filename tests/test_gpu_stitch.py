@@ -44,7 +44,9 @@ def device_runs(pts, row_index, cap=0):
 
 
 def default_cap(row_index):
-    return 64  # (a full leaf, whatever the chain length: rj_build_lbvh)
+    eb = edge_begin(row_index)
+    nc = len(eb) - 1
+    return 32 if nc and int(eb[-1]) // nc < 16 else 64  # (rj_build_lbvh: runs of 32 where the chains average fewer than 16 edges)
 
 
 def same(ref, got, what):

@@ -1,8 +1,8 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_strip.py tests/test_gpu_leaf_order.py -x -q 2>&1 | tail -4 || exit 1
+python -m pytest tests/test_gpu_strip.py tests/test_gpu_leaf_order.py tests/test_gpu_stitch.py -x -q 2>&1 | tail -4 || exit 1
 O=gpurun_out/r04_d_leaf_order.txt; : > $O
-for pair in "WaterBodiesLike BlockGroup 1:0" "LakesLike ParksLike 1:0" "Gaussian5M Gaussian1M 1:0"; do
+for pair in "WaterBodies BlockGroup 1:0" "WaterBodiesLike BlockGroup 1:0" "Gaussian5M Gaussian1M 1:0" "USCounty BlockGroup 1:0,1:0:0:0:1"; do
   set -- $pair
   timeout -k 10 400 python tools/leaf_order_probe.py --base $1 --query $2 --reps 3 --variants $3 >> $O 2>> gpurun_out/r04_d_leaf_order.err
   echo "--- $1 $2 rc=$?" >> $O
