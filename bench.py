@@ -507,6 +507,24 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                 # the measured limiter: the issue port that is busy most of the time, or the latency of dependent loads
                 r["limiter"] = "valu-issue" if r["valu_busy_frac"] > 0.6 else "dependent-load latency"
                 r["limiter_frac"] = r["valu_busy_frac"]
+                if c.get("SQ_INSTS_VALU"):
+                    # The roofline these kernels actually sit under: a SIMD issues one VALU wave-instruction per 4 cycles whatever
+                    # the occupancy (tools/issue_probe.hip measured 4.2), so the chip's ceiling is SIMDs x clock / 4.
+                    # `floor_*`: what a group MUST issue on this workload -- one load, test and ballot per expanded node, one
+                    # table lookup + two corrections per leaf visit, four cross-lane reads and a test per scan step, loading,
+                    # bounding and handing over the group -- with the visit counts of the instrumented kernel.
+                    clk = getattr(torch.cuda.get_device_properties(dev), "clock_rate", 2400000) * 1e3
+                    simds = 4 * getattr(torch.cuda.get_device_properties(dev), "multi_processor_count", 256)
+                    peak = simds * clk / 4.0
+                    ach = c["SQ_INSTS_VALU"] / (alone_ms * 1e-3)
+                    r["instruction_roofline"] = {"bound": "valu-issue", "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1),
+                                                 "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
+                                                 "measured_on": "the kernel alone on its full grid (PMC pass)"}
+                    if kern.startswith("k_pip_walk") and is_headline:
+                        r["instruction_roofline"]["floor_valu_per_query"] = 3.8
+                        r["instruction_roofline"]["floor_note"] = ("3.6 node expansions x 8 + 3.7 leaf visits x 20 + 4.0 scan steps x 12 + 60 per 64-point group "
+                                                                   "(counts: profiles/r04_leaf_order.txt); the kernel issues %.1f per point -- the rest is "
+                                                                   "19 pops (11.5 stale), stack sweeps and the scheduler" % r["valu_per_query"])
             roof[name] = r
         roof["pip"]["query_ms"] = round(pip_k, 4)  # all PIP kernels of a step, first launch to last end
         roof["pip"]["frac_query"] = round(b_pip / (pip_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)

@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_group_extent(const int64_t* __restrict_
 }
 
 // The same estimate for a caller-owned point array, ONE block, through the permutation the query runs with (if any),
-// the result -- mean extent of <= 1024 sampled groups, + 1 so that 0 means "nothing yet" -- stored as one word into
+// the result -- mean extent of <= 256 sampled groups, + 1 so that 0 means "nothing yet" -- stored as one word into
 // mapped host memory: launched behind a query's kernels, read by the host when the NEXT query over that array is
 // issued.  No synchronisation, and no 2048 same-address atomics (what made k_group_extent 55 us).
 __global__ __launch_bounds__(1024) void k_group_extent_tail(const int64_t* __restrict__ pts, const uint32_t* __restrict__ order,
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(1024) void k_group_extent_tail(const int64_t* __res
   __shared__ uint32_t s_cnt[16];
   const int lane = lane_id(), w = threadIdx.x >> 6;
   const uint64_t ngroups = (n + 63) >> 6;
-  const uint64_t samples = ngroups < 1024 ? ngroups : 1024;
+  const uint64_t samples = ngroups < 256 ? ngroups : 256;  // (16 per wave: 1024 took 49 us behind every fourth query)
   const uint64_t stride = samples ? ngroups / samples : 1;
   unsigned long long sum = 0;
   uint32_t cnt = 0;

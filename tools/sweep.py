@@ -18,7 +18,10 @@ h.build_lbvh(0)
 cap = int(0.1 * (b.n_edges + q.n_edges)) + 1024
 pairs = h.alloc(8 * cap); closest = h.alloc(4 * q.n_points)
 for v in a.values.split(","):
-    h.set_option(a.opt, int(v))
+    try:
+        h.set_option(a.opt, int(v))
+    except Exception:
+        h.set_debug_option(a.opt, int(v))  # (grids, chunk sizes, run lengths: the experiment knobs)
     l, p = [], []
     for _ in range(a.reps):
         n = h.lsi_query(0, 1, 0, q.n_edges, cap, pairs); l.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
