@@ -10,6 +10,8 @@
 // `rest`) -- so k_pip_exact follows it unchanged and the results are the walk's (tests/test_gpu_strip.py).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/iterator/reverse_iterator.hpp>
@@ -75,89 +77,120 @@ __global__ __launch_bounds__(256) void k_strip_finish(const uint64_t* __restrict
   }
 }
 
-// One query point per lane, 64 consecutive positions per wave (one todo mask per wave, as the walk writes them).
+// PTS query points per lane: a wave takes PTS x 64 consecutive positions (point set p = positions 64 p + lane of the
+// group; one todo mask per 64 positions, as the walk writes them).  The scans of a lane's points are independent chains
+// of dependent reads -- table, box, box, ... -- so running PTS of them side by side multiplies the reads in flight per
+// wave (the kernel has all 8 waves per SIMD already and is bound by the latency of those reads).
+template <int PTS>
 __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
-  __shared__ uint32_t cand_all[4][kWalkList * 64];
+  __shared__ uint32_t cand_all[4][PTS * kWalkList * 64];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const DeviceBvh& T = A.bvh;
   const DeviceStrips& S = T.strips;
   const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;
-  uint32_t* const cand = cand_all[wib];  // [kWalkList][64], bank = lane
-  const uint64_t ngroups = (A.n + 63) / 64;
+  uint32_t* const cand = cand_all[wib];  // [PTS][kWalkList][64], bank = lane
+  const uint64_t per_group = (uint64_t) PTS * 64;
+  const uint64_t ngroups = (A.n + per_group - 1) / per_group;
   const uint64_t wave = (blockIdx.x * (uint64_t) blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t) gridDim.x * blockDim.x) >> 6;
   // (the counters of the next launch of this kind on this stream are cleared here, as every walk does: k_lsi)
   if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;
   if (blockIdx.x == 0 && threadIdx.x == 8) *A.next_rest_count = 0;
   for (uint64_t g = wave; g < ngroups; g += nwaves) {
-    const uint64_t ipos = g * 64 + lane;
-    const bool valid = ipos < A.n;
-    const uint32_t ip = A.order ? (valid ? A.order[ipos] : 0u) : (uint32_t) ipos;
-    int32_t qx = 0, qy = 0;
-    if (valid) {
-      typedef long long ll2_t __attribute__((ext_vector_type(2)));
-      const ll2_t p = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip);
-      qx = quant(p.x);
-      qy = quant(p.y);
-    }
-    const bool live = valid && ray_has_sky(sky, qx, qy);  // (above the map's skyline: a certain miss)
-    const int32_t qym1 = qy > 0 ? qy - 1 : 0;
-    int32_t qbest = 0x7FFFFFFF;
-    const uint32_t cand_base = (uint32_t) lane;
-    uint32_t cand_at = cand_base;
-    int32_t sure_y0 = INT32_MIN;
-    // the strip's entries from the height bucket of the lowest y0 that can still reach up to the point
-    // (y0 >= qy - 1 - the tallest box of the strip); what lies below the point inside that bucket fails the test
-    uint32_t j = 0, jend = 0;
-    if (live) {
-      const uint32_t s = (uint32_t) qx >> kStripShift;
-      const int64_t from = (int64_t) qym1 - (int64_t) S.tall[s];
-      const uint32_t want = from > 0 ? (uint32_t) from : 0u;
-      j = S.ytab[(s << kStripYBits) | (want >> kStripYShift)];
-      jend = S.ytab[(s + 1) << kStripYBits];
-    }
-    while (j < jend) {
-      const QBox b = S.ebox[j];
-      if (b.y0 > qbest) break;  // everything further starts above the bound
-      if (((qx - b.x0) | (b.x1 - qx) | (b.y1 - qym1)) >= 0) {
-        // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
-        // ends below the start of the one certain hit held so far replaces it
-        const uint32_t slot = S.eslot[j];
-        const bool certain = b.x0 < qx && qx < b.x1 && b.y0 > qy;
-        const bool replace = certain && b.y1 < sure_y0;
-        const bool first = cand_at == cand_base;
-        const bool over = !replace && cand_at == cand_base + kWalkList * 64;
-        cand[(replace || over) ? cand_base : cand_at] = slot;
-        sure_y0 = (replace || (first && certain)) ? b.y0 : INT32_MIN;
-        cand_at += replace ? 0u : 64u;
-        const int32_t top = certain ? b.y1 + 1 : 0x7FFFFFFF;
-        qbest = over ? -1 : (top < qbest ? top : qbest);
-      }
-      j++;
-    }
-    // hand-over: exactly k_pip_walk's
-    const bool done = valid && (cand_at == cand_base || sure_y0 != INT32_MIN);
-    if (done) {
-      const bool hit = cand_at != cand_base;
-      const uint32_t slot = hit ? cand[lane] : 0u;
-      __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip);
-      if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip);
-    }
-    const uint32_t fill = (cand_at - cand_base) >> 6;
-    const bool listed = valid && !done && fill <= (uint32_t) kWalkList;
-    const bool rest = valid && !done && !listed;
-    if (listed) {
+    bool valid[PTS];
+    uint32_t ip[PTS], j[PTS], jend[PTS], cand_base[PTS], cand_at[PTS];
+    int32_t qx[PTS], qy[PTS], qym1[PTS], qbest[PTS], sure_y0[PTS];
 #pragma unroll
-      for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[lane + 64 * k] : 0xFFFFFFFFu;
+    for (int p = 0; p < PTS; p++) {
+      const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
+      valid[p] = ipos < A.n;
+      ip[p] = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
+      qx[p] = 0; qy[p] = 0;
+      if (valid[p]) {
+        typedef long long ll2_t __attribute__((ext_vector_type(2)));
+        const ll2_t pt = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip[p]);
+        qx[p] = quant(pt.x);
+        qy[p] = quant(pt.y);
+      }
+      qym1[p] = qy[p] > 0 ? qy[p] - 1 : 0;
+      qbest[p] = 0x7FFFFFFF;
+      cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
+      cand_at[p] = cand_base[p];
+      sure_y0[p] = INT32_MIN;
+      j[p] = jend[p] = 0;
     }
-    const uint64_t lm = __ballot(listed);
-    if (lane == 0) A.todo_mask[g] = lm;
-    const uint64_t rm = __ballot(rest);
-    if (rm) {
-      unsigned long long base = 0;
-      if (lane == 0) base = atomicAdd(A.rest_count, (unsigned long long) __popcll(rm));
-      base = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) base);
-      if (rest) A.rest[base + rank_below(rm)] = ip;
+    // the strip's entries from the height bucket of the lowest y0 that can still reach up to the point
+    // (y0 >= qy - 1 - the tallest box of the strip); what lies below the point inside that bucket fails the test.
+    // (A sentinel entry behind every strip instead of reading where the strip ends was tried: a lane that is done
+    //  cannot stop reading without a branch around the loads, and the pass is bound by the number of random reads:
+    //  2.61 / 4.58 ms against 2.42 / 4.01.)
+#pragma unroll
+    for (int p = 0; p < PTS; p++) {
+      if (valid[p] && ray_has_sky(sky, qx[p], qy[p])) {  // (above the map's skyline: a certain miss)
+        const uint32_t s = (uint32_t) qx[p] >> kStripShift;
+        const int64_t from = (int64_t) qym1[p] - (int64_t) S.tall[s];
+        const uint32_t want = from > 0 ? (uint32_t) from : 0u;
+        j[p] = S.ytab[(s << kStripYBits) | (want >> kStripYShift)];
+        jend[p] = S.ytab[(s + 1) << kStripYBits];
+      }
+    }
+    for (;;) {
+      bool more = false;
+      QBox b[PTS];
+#pragma unroll
+      for (int p = 0; p < PTS; p++)   // (the reads of all points first: they are what the lane waits for)
+        if (j[p] < jend[p]) b[p] = S.ebox[j[p]];
+#pragma unroll
+      for (int p = 0; p < PTS; p++) {
+        if (j[p] >= jend[p]) continue;
+        if (b[p].y0 > qbest[p]) { j[p] = jend[p]; continue; }  // everything further starts above the bound
+        if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p])) >= 0) {
+          // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
+          // ends below the start of the one certain hit held so far replaces it
+          const uint32_t slot = S.eslot[j[p]];
+          const bool certain = b[p].x0 < qx[p] && qx[p] < b[p].x1 && b[p].y0 > qy[p];
+          const bool replace = certain && b[p].y1 < sure_y0[p];
+          const bool first = cand_at[p] == cand_base[p];
+          const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
+          cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot;
+          sure_y0[p] = (replace || (first && certain)) ? b[p].y0 : INT32_MIN;
+          cand_at[p] += replace ? 0u : 64u;
+          const int32_t top = certain ? b[p].y1 + 1 : 0x7FFFFFFF;
+          qbest[p] = over ? -1 : (top < qbest[p] ? top : qbest[p]);
+        }
+        j[p]++;
+        more = more || j[p] < jend[p];
+      }
+      if (!more) break;
+    }
+    // hand-over, per point set: exactly k_pip_walk's
+#pragma unroll
+    for (int p = 0; p < PTS; p++) {
+      const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
+      const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
+      if (done) {
+        const bool hit = cand_at[p] != cand_base[p];
+        const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
+        __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip[p]);
+        if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip[p]);
+      }
+      const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
+      const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
+      const bool rest = valid[p] && !done && !listed;
+      if (listed) {
+#pragma unroll
+        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
+      }
+      const uint64_t lm = __ballot(listed);
+      const uint64_t g64 = g * PTS + p;  // the 64-position group this set is
+      if (lane == 0 && g64 * 64 < A.n) A.todo_mask[g64] = lm;
+      const uint64_t rm = __ballot(rest);
+      if (rm) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(A.rest_count, (unsigned long long) __popcll(rm));
+        base = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) base);
+        if (rest) A.rest[base + rank_below(rm)] = ip[p];
+      }
     }
     wave_lds_fence();  // (the lists are reused by the next group)
   }
@@ -216,10 +249,16 @@ hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* c
 }
 
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus) {
-  const uint64_t ngroups = (a.n + 63) / 64;
+  // two points per lane where the query set keeps every resident wave busy with at least two 128-position groups
+  // (measured, first pass alone: 2.68 -> 2.42 ms on the lake-shaped base, 4.66 -> 4.01 lakes x parks; four per lane --
+  //  86 VGPRs, 5 waves per SIMD -- 3.27 / 5.66: the pass is bound by the number of random reads, not by their latency)
+  const uint64_t resident_waves = (uint64_t) cus * 32;
+  const int pts = a.n >= resident_waves * 2 * 128 ? 2 : 1;
+  const uint64_t ngroups = (a.n + (uint64_t) pts * 64 - 1) / ((uint64_t) pts * 64);
   int grid = blocks_for(ngroups, 4, cus * 8);
   if (grid > max_blocks) grid = max_blocks;
-  hipLaunchKernelGGL(k_pip_strip, dim3(grid), dim3(256), 0, st, a);
+  if (pts == 2) hipLaunchKernelGGL(k_pip_strip<2>, dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_pip_strip<1>, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();
 }
 
