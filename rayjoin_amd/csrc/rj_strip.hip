@@ -3,7 +3,7 @@
 // Built for maps of isolated rings, where the box hierarchy is at its worst for upward rays: a leaf block of a few
 // rings is mostly gaps in x, and a point opens every block over its column whose x-extent contains it until one
 // holds an edge at its x -- measured on the lake-shaped stand-in: 20 leaf blocks opened per point, one segment box
-// tested.  Here a point reads its strip's list: one table read for its height (256 buckets per strip), then the
+// tested.  Here a point reads its strip's list: one table read for its height (1024 buckets per strip), then the
 // entries' boxes upwards -- consecutive 16-byte reads -- until a certain hit bounds the answer.  (First version: a
 // binary search over 8-byte keys, then key -> slot -> box per entry: 4.9 ms for the 29.7 M lattice vertices.)  The pass is k_pip_walk's in every other respect -- integer tests only, the same
 // certain-hit pruning, the same hand-over (settled points written, candidate lists in `todo`, overflowed lists in
