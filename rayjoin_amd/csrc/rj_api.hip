@@ -1799,7 +1799,9 @@ int rj_comm_init(rj_handle h, int nranks, int rank, const uint8_t id[RJ_COMM_ID_
   memcpy(u.internal, id, RJ_COMM_ID_BYTES);
   RJ_NCCL(h, ncclCommInitRank(&h->comm, nranks, u, rank));
   // the second communicator (point queues): same ranks, its own stream -- collective on every rank, like the first
-  RJ_NCCL(h, ncclCommSplit(h->comm, 0, rank, &h->comm2, nullptr));
+  // (should a RCCL build refuse the split, the point queues share the first communicator AND its stream: serialised
+  //  behind the pair exchange, never concurrent with it)
+  if (ncclCommSplit(h->comm, 0, rank, &h->comm2, nullptr) != ncclSuccess) h->comm2 = nullptr;
   h->nranks = nranks;
   h->rank = rank;
   if (int r = dev_alloc(h, &h->d_counts, 2 * (uint64_t) nranks)) return r;
@@ -2018,23 +2020,25 @@ int rj_exchange_pairs_finish(rj_handle h, int buf, uint64_t* counts_out, const u
 
 int rj_exchange_u32_begin(rj_handle h, const uint32_t* src_dev, uint64_t n_per_rank, uint32_t* recv_dev) {
   RJ_CHECK_H(h);
-  if (!h->comm2) return fail(h, RJ_E_INVALID, "rj_exchange_u32_begin: call rj_comm_init first");
+  if (!h->comm) return fail(h, RJ_E_INVALID, "rj_exchange_u32_begin: call rj_comm_init first");
   if (n_per_rank && (!src_dev || !recv_dev)) return fail(h, RJ_E_INVALID, "rj_exchange_u32_begin: null buffer");
   if (int r = set_device(h)) return r;
+  ncclComm_t c = h->comm2 ? h->comm2 : h->comm;
+  hipStream_t cs = h->comm2 ? h->comm_stream2 : h->comm_stream;
   // behind everything enqueued so far on BOTH of the handle's streams (the PIP kernels run on either)
   RJ_HIP(h, hipEventRecord(h->ev_comm2, h->stream));
-  RJ_HIP(h, hipStreamWaitEvent(h->comm_stream2, h->ev_comm2, 0));
+  RJ_HIP(h, hipStreamWaitEvent(cs, h->ev_comm2, 0));
   RJ_HIP(h, hipEventRecord(h->ev_comm2_aux, h->aux_stream));
-  RJ_HIP(h, hipStreamWaitEvent(h->comm_stream2, h->ev_comm2_aux, 0));
-  if (n_per_rank) RJ_NCCL(h, ncclAllGather(src_dev, recv_dev, n_per_rank, ncclUint32, h->comm2, h->comm_stream2));
+  RJ_HIP(h, hipStreamWaitEvent(cs, h->ev_comm2_aux, 0));
+  if (n_per_rank) RJ_NCCL(h, ncclAllGather(src_dev, recv_dev, n_per_rank, ncclUint32, c, cs));
   return RJ_OK;
 }
 
 int rj_exchange_u32_finish(rj_handle h) {
   RJ_CHECK_H(h);
-  if (!h->comm2) return fail(h, RJ_E_INVALID, "rj_exchange_u32_finish: call rj_comm_init first");
+  if (!h->comm) return fail(h, RJ_E_INVALID, "rj_exchange_u32_finish: call rj_comm_init first");
   if (int r = set_device(h)) return r;
-  RJ_HIP(h, hipStreamSynchronize(h->comm_stream2));
+  RJ_HIP(h, hipStreamSynchronize(h->comm2 ? h->comm_stream2 : h->comm_stream));
   return RJ_OK;
 }
 
