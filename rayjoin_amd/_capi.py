@@ -433,4 +433,5 @@ class Handle:
         self._check(self.L.rj_last_stats(self.h, s))
         return dict(leaf_blocks=s[0], exact_tests=s[1], nodes_expanded=s[2], leaf_box_tests=s[3],
                     cyc_total=s[4], cyc_node=s[5], cyc_leaf=s[6], cyc_drain=s[7], merge_rounds=s[8],
-                    cyc_max_wave=s[9], cyc_sched=s[10], cyc_head=s[11], cyc_tail=s[12], stale_pops=s[13], leaf_visits_without_candidates=s[14], leaf_interested_lanes=s[15])
+                    cyc_max_wave=s[9], cyc_sched=s[10], cyc_head=s[11], cyc_tail=s[12], stale_pops=s[13], leaf_visits_without_candidates=s[14], leaf_interested_lanes=s[15],
+                    walk_stack_max=s[8])  # (k_pip_walk<STATS>: the deepest stack any group reached; k_lsi: merge_rounds)

@@ -143,10 +143,6 @@ struct rj_handle_s {
   int flip_lsi = 0, flip_pip[2] = {0, 0};  // which of the two counter sets the next launch uses (LSI; PIP on main / aux stream)
   // PIP in two passes (rj_kernels.hip, k_pip_walk): the integer-only walk settles what it can, k_pip takes the rest
   int pip_walk = 1;                        // "pip_walk": 1 auto (default), 0 k_pip alone, 2 always both passes
-  // k_pip_walk2 on a tree of more than 3 levels keeps 4 candidate slots per point instead of 6 (its stack is larger):
-  // where that overflows too many lists the one-point kernel takes the query size back (decided again with the schedule)
-  bool last_tall[2] = {false, false};      // the last walk on main / aux was such a one
-  uint64_t tall_bad_n = 0;                 // the query size for which it left too many lists over (0: none)
   int last_walk_points = 1;                // ... and how many points a lane of its walk took
   int last_passes = 0;                     // kernels of the last PIP query (3 or 1)
   int flip_walk[2] = {0, 0};
@@ -175,6 +171,7 @@ struct rj_handle_s {
   uint32_t* h_fault = nullptr;
   uint32_t* d_fault = nullptr;              // the same memory as the device sees it
   int debug_stack_cap = 1 << 30;            // tests of the fault path only
+  int debug_walk_stack = 0;                 // tests of the groups that leave the walk (0: kWalkStack entries)
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
@@ -359,7 +356,6 @@ static void co_reset(rj_handle h) {
   h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0;
   h->co_ratio = 0.46f;
   h->co_L = h->co_best_L = 0;
-  h->tall_bad_n = 0;
 }
 static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
   if (!h->co_measure) return;
@@ -682,6 +678,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
       {"lsi_share_blocks", &h->lsi_share_set, 0, 1 << 20},  // fixed grids of the shared schedule (0: derived)
       {"pip_share_blocks", &h->pip_share_set, 0, 1 << 20},
       {"stack_cap", &h->debug_stack_cap, 1, 1 << 30},     // instrumented kernels: fewer traversal-stack entries (fault path)
+      {"walk_stack", &h->debug_walk_stack, 0, 1 << 30},   // k_pip_walk*: fewer stack entries (groups that need more leave the walk)
       {"run_cap", &h->debug_run_cap, 0, 64},              // edges per polyline run of the next first build of a map (0: 64)
       {"pack_solo", &h->debug_pack_solo, 0, 64},          // a run longer than this never shares its leaf (0: 48)
       {"pack_spread", &h->debug_pack_spread, 0, 1000000}, // a shared leaf may be this many times as large as its runs (0: 8)
@@ -711,6 +708,7 @@ int rj_get_debug_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_set;
   else if (!strcmp(name, "pip_share_blocks")) *value = h->pip_share_set;
   else if (!strcmp(name, "stack_cap")) *value = h->debug_stack_cap;
+  else if (!strcmp(name, "walk_stack")) *value = h->debug_walk_stack;
   else if (!strcmp(name, "run_cap")) *value = h->debug_run_cap;
   else if (!strcmp(name, "pack_solo")) *value = h->debug_pack_solo;
   else if (!strcmp(name, "pack_spread")) *value = h->debug_pack_spread;
@@ -1508,6 +1506,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   a.chunk_groups = (uint32_t) h->chunk_groups;  // (0: the launch wrappers pick it by the size of the query set)
   a.group_lanes = (uint32_t) h->group_lanes;
   a.stack_cap = h->debug_stack_cap;
+  a.walk_stack = h->debug_walk_stack;
   a.stats = h->stats_on ? h->d_stats : nullptr;
   a.rest = nullptr; a.rest_count = nullptr; a.next_rest_count = nullptr; a.n_dev = nullptr;
   a.todo = nullptr; a.todo_mask = nullptr;
@@ -1534,7 +1533,6 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   for (int k : {si, 1 - si})
     if (seen == ~0ull && h->walk_n[k] == n && h->h_rest[k] != ~0ull) {
       seen = h->h_rest[k];
-      if (h->last_tall[k] && seen > 8192) h->tall_bad_n = n;  // (4-slot lists overflow too often on this pair)
     }
   // "auto" drops the first pass where it does not pay: most points left over, or many overflowed lists in absolute
   // terms -- k_pip locates those one scattered handful per wave (the list is in no useful order), which on the gaussian
@@ -1575,15 +1573,11 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     w.todo = h->todo[si]; w.todo_mask = h->todo_mask[si];
     if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
     // Two points per lane (k_pip_walk2: one traversal per 128 positions) where the query set is large enough for full
-    // 64-position groups and nobody is counting visits: headline step -5.5 %, Zipcode -6 %, nested -5 %.  On a tree of
-    // more than 3 levels the larger stack leaves room for 4 candidate slots per point instead of 6 (six blocks per CU
-    // either way): LakesNA step -8 %, but on WaterBodies 13.8 k lists overflow instead of 264 and the step is 18 %
-    // slower -- so a query size whose 4-slot run left more than 8 Ki lists over goes back to the one-point kernel.
-    const bool tall = w.bvh.top > 3;  // (k_pip_walk2 then keeps 4 candidate slots per point, see walk2_list)
+    // 64-position groups and nobody is counting visits: headline step -5.5 %, Zipcode -6 %, nested -5 %.  (The walk's
+    // stack is cut at kWalkStack entries whatever the tree's height, so eight blocks per CU fit on every tree.)
     const bool two = h->walk_points == 2 && !h->stats_on && w.group_lanes == 64 && !h->chunk_groups &&
-                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6 && !(tall && h->tall_bad_n == n) &&
+                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6 &&
                      n >= (uint64_t) 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top);  // (two 128-position groups per resident wave)
-    h->last_tall[si] = two && tall;
     tic(h, RJ_T_PIP_WALK, st);
     // a base map with a column index (isolated rings): the first pass reads the point's strip instead of walking the tree
     const bool columns = w.bvh.strips.ytab != nullptr && !h->stats_on;

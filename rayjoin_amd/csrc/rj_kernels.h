@@ -58,6 +58,7 @@ struct PipArgs {
   uint32_t chunk_groups;
   uint32_t group_lanes;  // points per wave (0 = choose from the point count)
   int stack_cap;         // instrumented kernel only: use fewer stack entries (tests of the fault path)
+  int walk_stack;        // k_pip_walk*: use fewer than kWalkStack entries (0: all; tests of the groups that leave the walk)
   unsigned long long* stats;
   // k_pip_walk hand-over.  A point the walk could not settle with integer tests alone leaves its complete candidate
   // list in `todo` (one 16-byte slot per query POSITION, a 64-bit mask per group says which are filled: no atomics,

@@ -1573,7 +1573,16 @@ __global__ __launch_bounds__(64 * kPipWaves, 6) void k_pip(PipArgs A) {
 // Pruning is exactly k_pip's (certain hits bound a lane; a certain hit below the held one replaces it),
 // so whatever is settled here is what k_pip would have answered.
 // =============================================================================================
-__host__ __device__ __forceinline__ int walk_stack_entries(int top) { return 64 + 63 * (top > 1 ? top - 1 : 0) + 3; }
+// The walk's stack: the worst case of a 64-ary tree is 64 + 63 (top - 1) entries; measured on every stand-in pair a 64-point
+// group never holds more than 94 (USCounty 53, WaterBodies 68, LakesNA 77, the gaussian polygons 94).  The stack is cut at
+// kWalkStack entries whatever the height, and a group that would need more LEAVES THE WALK: its points go to the rest
+// list, which k_pip_exact's first blocks locate with k_pip's traversal (worst-case stack).  That is what lets eight
+// blocks of k_pip_walk2 share a CU's LDS with six candidate slots per point on a tree of any height.
+constexpr int kWalkStack = 124;
+__host__ __device__ __forceinline__ int walk_stack_entries(int top) {
+  const int worst = 64 + 63 * (top > 1 ? top - 1 : 0) + 3;
+  return worst < kWalkStack ? worst : kWalkStack;
+}
 __host__ __device__ __forceinline__ size_t walk_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256; }
 
 template <bool STATS>
@@ -1583,9 +1592,10 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
   const int wib = threadIdx.x >> 6;
   const DeviceBvh& T = A.bvh;
   const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;  // (exhaustive, or not used)
-  const int stack_cap = walk_stack_entries(T.top);
+  const int stack_entries = walk_stack_entries(T.top);
+  const int stack_cap = A.walk_stack > 0 && A.walk_stack < stack_entries ? A.walk_stack : stack_entries;
   uint4* const stack = walk_smem + (size_t) wib * (walk_wave_lds(T.top) / 16);
-  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [kWalkList][64], bank = lane
+  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_entries);  // [kWalkList][64], bank = lane
   const uint32_t stack_lds = (uint32_t) (uintptr_t) stack;  // the stack's LDS byte address (the low half of the generic pointer)
   const uint32_t GL = A.group_lanes;
   const uint64_t ngroups = (A.n + GL - 1) / GL;
@@ -1639,15 +1649,17 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
       }
       return keep;
     };
-    int sp = 0;
+    int sp = 0, sp_max = 0;
+    bool ovf = false;  // wave-uniform: the stack would not hold this group's traversal
     {
       const QBox b = T.lvl[T.top][lane];
       const uint64_t higher = sibling_order(T, T.top)[lane];
       uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
-      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+      if (__popcll(m) > stack_cap) { m = 0; ovf = true; }
       if ((m >> lane) & 1)
         stack[__popcll(m & higher)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
       sp = __popcll(m);
+      sp_max = sp;
       wave_lds_fence();
     }
     if (STATS) tk_head += clock64() - tkg;
@@ -1660,7 +1672,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
       uint4 ent;
       asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ent) : "v"(stack_lds + (uint32_t) sp * 16u) : "memory");
       const int32_t ey0 = (int32_t) ent.y, ex0 = (int32_t) ent.z, ex1 = (int32_t) ent.w;
-      const bool want = ((qx - ex0) | (ex1 - qx) | (qbest - ey0)) >= 0;  // stale entries die here, untouched
+      const bool want = ((uint32_t) (qx - ex0) <= (uint32_t) (ex1 - ex0)) & (qbest >= ey0);  // stale entries die here, untouched
       if (!__ballot(want)) {
         if (STATS) st_stale++;
         continue;
@@ -1673,13 +1685,14 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
         const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
         const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane];
         uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
-        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+        if (sp + __popcll(m) > stack_cap) { ovf = true; break; }  // (the group leaves the walk: see kWalkStack)
         if ((m >> lane) & 1)
           stack[sp + __popcll(m & higher)] =
               make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
         sp += __popcll(m);
         wave_lds_fence();
         if (STATS) {
+          sp_max = sp > sp_max ? sp : sp_max;
           st_nodes++;
           tk_node += clock64() - tk0;
         }
@@ -1719,8 +1732,8 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
           const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, bb.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, bb.x1);
           const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, bb.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, bb.y1);
           if (STATS) st_box++;
-          // ray_can_hit and "still inside my range" as one sign test
-          if (((qx - sx0) | (sx1 - qx) | (sy1 - qym1) | (qbest - sy0) | (j - jlo)) >= 0) {
+          // ray_can_hit and "still inside my range" (compares joined on the scalar side: fewer VALU than one sign test)
+          if ((sx0 <= qx) & (qx <= sx1) & (sy1 >= qym1) & (qbest >= sy0) & (j >= jlo)) {
             // certain hit (strictly inside in x, strictly above) => its box top bounds the answer; one that ends below
             // the start of the one certain hit held so far replaces it (that one is certainly higher)
             const bool certain = sx0 < qx && qx < sx1 && sy0 > qy;
@@ -1764,7 +1777,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     const long long tkt = STATS ? clock64() : 0;
     // settled: nothing above the point, or exactly one candidate and it is a certain hit (every other
     // edge over this x was pruned because it starts above that candidate's box top)
-    const bool done = valid && (cand_at == cand_base || sure_y0 != INT32_MIN);
+    const bool done = valid && !ovf && (cand_at == cand_base || sure_y0 != INT32_MIN);
     if (done) {
       const bool hit = cand_at != cand_base;
       const uint32_t slot = hit ? cand[lane] : 0u;
@@ -1776,7 +1789,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     // One slot per query position and one mask per group: nothing to contend for (an append counter shared by
     // 450 k groups, most of which have something to hand over on a map pair with shared vertices, stalls them all).
     const uint32_t fill = (cand_at - cand_base) >> 6;
-    const bool listed = valid && !done && fill <= (uint32_t) kWalkList;
+    const bool listed = valid && !done && !ovf && fill <= (uint32_t) kWalkList;
     const bool rest = valid && !done && !listed;
     if (listed) {
 #pragma unroll
@@ -1793,6 +1806,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     }
     wave_lds_fence();  // (the lists are reused by the next group)
     if (STATS) {
+      if (lane == 0 && A.stats) atomicMax(&A.stats[8], (unsigned long long) sp_max);  // (the deepest stack: what kWalkStack is sized by)
       st_rest += (unsigned long long) __popcll(rm);
       tk_tail += clock64() - tkt;
     }
@@ -1819,26 +1833,23 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 // k_pip_walk with TWO points per lane: a wave takes 128 consecutive query positions (lane l: positions l and 64 + l of
 // the group) through ONE traversal -- node expansions, pops, the leaf blocks' loads and bucket-table reads are shared,
 // the per-point work (pop-time test, bucket lookup, scan, candidate bookkeeping) is done per point set, and a set none
-// of whose lanes wants a leaf block skips it (wave-uniform).  Same stack bound, twice the candidate lists; the hand-over
+// of whose lanes wants a leaf block skips it (wave-uniform).  Same stack, twice the candidate lists; the hand-over
 // (one todo slot per position, one mask per 64 positions, the rest list) is exactly k_pip_walk's, so k_pip_exact
 // cannot tell the two apart.  Requires group_lanes == 64 (a large query set).
-// (LIST = candidate slots a lane keeps per point: kWalkList where the stack leaves room, 4 for the taller trees -- the
-//  todo record always holds kWalkList slots, the unused ones stay empty; more overflowed lists, one more block per CU)
-__host__ __device__ __forceinline__ int walk2_list(int top) { return top <= 3 ? kWalkList : 4; }
-__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) walk2_list(top) * 256 * 2; }
+__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256 * 2; }
 
 // (96 SGPRs: above that the hardware admits one block per CU fewer than the occupancy query reports, and the shared
 //  schedule's 5 walk + 2 k_lsi2 blocks per CU no longer fit -- the skyline pointer took it to 100: 0.785 -> 0.852 ms)
-template <int LIST>
-__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk2(PipArgs A) {
+__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk2(PipArgs A) {
   extern __shared__ uint4 walk_smem[];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const DeviceBvh& T = A.bvh;
   const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;  // (exhaustive, or not used)
-  const int stack_cap = walk_stack_entries(T.top);
+  const int stack_entries = walk_stack_entries(T.top);
+  const int stack_cap = A.walk_stack > 0 && A.walk_stack < stack_entries ? A.walk_stack : stack_entries;
   uint4* const stack = walk_smem + (size_t) wib * (walk2_wave_lds(T.top) / 16);
-  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_cap);  // [2][LIST][64], bank = lane
+  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_entries);  // [2][kWalkList][64], bank = lane
   const uint32_t stack_lds = (uint32_t) (uintptr_t) stack;
   const uint64_t ngroups = (A.n + 127) / 128;
   const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
@@ -1868,7 +1879,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       }
       qym1[p] = qy[p] > 0 ? qy[p] - 1 : 0;
       qbest[p] = valid[p] ? 0x7FFFFFFF : -1;
-      cand_base[p] = (uint32_t) lane + (uint32_t) p * (LIST * 64);
+      cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
       cand_at[p] = cand_base[p];
       sure_y0[p] = INT32_MIN;
     }
@@ -1903,11 +1914,12 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       return keep;
     };
     int sp = 0;
+    bool ovf = false;  // wave-uniform: the stack would not hold this group's traversal
     {
       const QBox b = T.lvl[T.top][lane];
       const uint64_t higher = sibling_order(T, T.top)[lane];
       uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
-      if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+      if (__popcll(m) > stack_cap) { m = 0; ovf = true; }
       if ((m >> lane) & 1)
         stack[__popcll(m & higher)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
       sp = __popcll(m);
@@ -1918,9 +1930,12 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       uint4 ent;
       asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ent) : "v"(stack_lds + (uint32_t) sp * 16u) : "memory");
       const int32_t ey0 = (int32_t) ent.y, ex0 = (int32_t) ent.z, ex1 = (int32_t) ent.w;
+      // (compares, not sign bits: 3 VALU + 1 SALU per set where the sign test took 5 VALU, and 15 of a group's 25 pops
+      //  end right here)
+      const uint32_t ew = (uint32_t) (ex1 - ex0);
       bool want[2];
 #pragma unroll
-      for (int p = 0; p < 2; p++) want[p] = ((qx[p] - ex0) | (ex1 - qx[p]) | (qbest[p] - ey0)) >= 0;
+      for (int p = 0; p < 2; p++) want[p] = ((uint32_t) (qx[p] - ex0) <= ew) & (qbest[p] >= ey0);
       if (!__ballot(want[0] || want[1])) continue;  // stale: untouched
       const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
       const int lvl = (int) (e >> 28);
@@ -1929,7 +1944,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
         const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane];
         uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
-        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultPipStack, lane)) m = 0;
+        if (sp + __popcll(m) > stack_cap) { ovf = true; break; }  // (the group leaves the walk: see kWalkStack)
         if ((m >> lane) & 1)
           stack[sp + __popcll(m & higher)] =
               make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
@@ -1959,16 +1974,16 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
           j = want[p] ? j : -1;
           jlo = want[p] ? jlo : 0;
           const int32_t qbest_before = qbest[p];
-          while (__ballot(j >= jlo)) {
+          auto scan_step = [&]() {
             const int jj = j & 63;
             const int ja = j << 2;
             const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, bb.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, bb.x1);
             const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, bb.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, bb.y1);
-            if (((qx[p] - sx0) | (sx1 - qx[p]) | (sy1 - qym1[p]) | (qbest[p] - sy0) | (j - jlo)) >= 0) {
+            if ((sx0 <= qx[p]) & (qx[p] <= sx1) & (sy1 >= qym1[p]) & (qbest[p] >= sy0) & (j >= jlo)) {
               const bool certain = sx0 < qx[p] && qx[p] < sx1 && sy0 > qy[p];
               const bool replace = certain && sy1 < sure_y0[p];
               const bool first = cand_at[p] == cand_base[p];
-              const bool over = !replace && cand_at[p] == cand_base[p] + LIST * 64;
+              const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
               cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot0 + (uint32_t) jj;
               sure_y0[p] = (replace || (first && certain)) ? sy0 : INT32_MIN;
               cand_at[p] += replace ? 0u : 64u;
@@ -1976,6 +1991,12 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
               qbest[p] = over ? -1 : (top < qbest[p] ? top : qbest[p]);
             }
             j--;
+          };
+          // (a visit takes 1.1 steps: the first one stands outside the loop, where it carries no copies of the three
+          //  values the loop hands from step to step)
+          if (__ballot(j >= jlo)) {
+            scan_step();
+            while (__ballot(j >= jlo)) scan_step();
           }
           changed = changed || qbest[p] != qbest_before;
         }
@@ -2005,7 +2026,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
-      const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
+      const bool done = valid[p] && !ovf && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
       if (done) {
         const bool hit = cand_at[p] != cand_base[p];
         const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
@@ -2013,11 +2034,11 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip[p]);
       }
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
-      const bool listed = valid[p] && !done && fill <= (uint32_t) LIST;
+      const bool listed = valid[p] && !done && !ovf && fill <= (uint32_t) kWalkList;
       const bool rest = valid[p] && !done && !listed;
       if (listed) {
 #pragma unroll
-        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (k < LIST && (uint32_t) k < fill) ? cand[cand_base[p] + 64 * (k < LIST ? k : 0)] : 0xFFFFFFFFu;
+        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
       }
       const uint64_t lm = __ballot(listed);
       const uint64_t g64 = (uint64_t) g32 * 2 + p;  // the 64-position group this set is
@@ -2409,7 +2430,7 @@ hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int 
 int pip_walk2_blocks_per_cu(int top) {
   const size_t block = 4 * walk2_wave_lds(top) + 64;
   const size_t by_lds = (size_t) 160 * 1024 / block;
-  return (int) (by_lds < 6 ? by_lds : 6);
+  return (int) (by_lds < 8 ? by_lds : 8);
 }
 
 // ... beside `lsi_blocks_per_cu` resident blocks of k_lsi (17.5 KiB of LDS and one wave slot per SIMD each)
@@ -2418,6 +2439,10 @@ int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu) {
   const size_t left = (size_t) 160 * 1024 > (size_t) lsi_blocks_per_cu * 17920 ? (size_t) 160 * 1024 - (size_t) lsi_blocks_per_cu * 17920 : 0;
   int n = (int) (left / block);
   if (n > 8 - lsi_blocks_per_cu) n = 8 - lsi_blocks_per_cu;
+  // ... and 80 of a SIMD's 512 VGPRs per wave of k_lsi2, 64 per wave of the walk: 5 beside 2.  (Tried: k_lsi2 held to
+  // 64 VGPRs so that 6 fit -- 14 spilled registers make it 48 % slower, and the walk gains nothing from the sixth block.)
+  const int by_vgpr = (512 - lsi_blocks_per_cu * 80) / 64;
+  if (n > by_vgpr) n = by_vgpr;
   if (n > pip_walk2_blocks_per_cu(top)) n = pip_walk2_blocks_per_cu(top);
   return n < 1 ? 1 : n;
 }
@@ -2431,10 +2456,7 @@ hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a_in, int max_blocks,
   a.chunk_groups = a.chunk_groups ? a.chunk_groups : 3;  // (128-point groups: the same 6 x 64 positions per chunk)
   const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
-  if (walk2_list(a.bvh.top) == kWalkList)
-    hipLaunchKernelGGL(k_pip_walk2<kWalkList>, dim3(grid), dim3(256), lds, st, a);
-  else
-    hipLaunchKernelGGL(k_pip_walk2<4>, dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(k_pip_walk2, dim3(grid), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

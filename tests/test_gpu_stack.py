@@ -124,3 +124,44 @@ def test_stack_overflow_is_reported_not_corrupted(oracle):
         h.pip_query(0, 1, None, 0, q.n_points, closest, None)
         assert np.array_equal(closest.to_host(np.uint32), oracle.pip_brute(m0, 1, q.pts))
     dctx.close()
+
+
+@pytest.mark.parametrize("walk_points", [1, 2])
+def test_groups_that_outgrow_the_walks_stack_leave_the_walk(oracle, walk_points):
+    """The walk's stack is 124 entries whatever the tree's height (rj_kernels.hip, kWalkStack: measured depths stay
+    below 94), and a group that would need more hands ALL its points to the rest list, which k_pip_exact's first
+    blocks locate with k_pip's worst-case stack.  With the stack shrunk to a few entries most groups take that way
+    out: closest edges and face ids (pip_lbvh.h:25-142 semantics) must not change, with one and with two points per
+    lane, synchronous and asynchronous."""
+    oracle.lib().rjo_set_num_threads(16)
+    scale = 0.12 if walk_points == 1 else 0.3  # (two points per lane: from two 128-position groups per resident wave on)
+    ctx = maps.Context([synth.standin("USCounty", scale), synth.standin("BlockGroup", scale)]).load()
+    b, q = ctx.maps
+    m0 = oracle.Map(b.pts, b.row_index, b.left, b.right)
+    want = oracle.pip_grid(m0, 0, q.pts, 512)
+    want_faces = m0.face_ids(want)
+    h = _capi.Handle(0)
+    try:
+        h.upload_map(0, b.pts, b.row_index, b.left, b.right)
+        h.upload_map(1, q.pts, q.row_index, q.left, q.right)
+        h.build_lbvh(0)
+        h.set_option("pip_walk", 2)
+        h.set_option("pip_walk_points", walk_points)
+        closest, faces = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+        left = {}
+        for cap in (0, 6, 2, 1):
+            h.set_debug_option("walk_stack", cap)
+            for sync in (True, False):
+                closest.from_host(np.full(q.n_points, 0xDEADBEEF, dtype=np.uint32))
+                faces.from_host(np.full(q.n_points, -7, dtype=np.int32))
+                h.pip_query(0, 1, None, 0, q.n_points, closest, faces, sync=sync)
+                h.sync()
+                assert h.get_option("pip_last_walk_points") == walk_points
+                assert np.array_equal(closest.to_host(np.uint32), want), (cap, sync)
+                assert np.array_equal(faces.to_host(np.int32), want_faces), (cap, sync)
+            left[cap] = h.get_option("pip_rest")
+        # the full stack leaves (next to) nothing over, one entry nearly everything
+        assert left[0] < q.n_points // 100
+        assert left[1] > q.n_points // 2 and left[1] >= left[2] >= left[6] >= left[0]
+    finally:
+        h.close()

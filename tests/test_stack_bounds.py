@@ -148,3 +148,11 @@ def test_lds_budget_keeps_the_occupancy():
     assert waves == 4 and "__shared__ unsigned long long ranges[kPipWaves];" in src
     assert 7 * lsi_block <= 160 * 1024
     assert 6 * pip_block <= 160 * 1024
+    # the walk: a stack cut at kWalkStack entries whatever the height (a group that needs more leaves the walk for k_pip,
+    # whose stack IS the worst case) + kWalkList candidate slots per point; eight four-wave blocks of either kernel per CU
+    wstack = int(re.search(r"constexpr int kWalkStack = (\d+);", src).group(1))
+    wlist = int(re.search(r"#define RJ_WALK_LIST (\d+)", open(HDR).read()).group(1))
+    assert 64 < wstack <= c["kPipStack"]
+    assert 8 * (4 * (16 * wstack + wlist * 256) + 32) <= 160 * 1024       # k_pip_walk
+    assert 8 * (4 * (16 * wstack + 2 * wlist * 256) + 32) <= 160 * 1024   # k_pip_walk2
+    assert "if (sp + __popcll(m) > stack_cap) { ovf = true; break; }" in src
