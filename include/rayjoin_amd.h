@@ -303,7 +303,7 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  * "skyline"          -1 / 0 / 1               the per-x-bucket top of the map that proves a PIP miss without a traversal:
  *                                             -1 built where most chains are closed rings, 0 never, 1 always.
  * "pip_columns"      -1 / 0 / 1               a second index for PIP on the NEXT rj_build_lbvh: the map's runs listed per
- *                                             vertical strip of 2^16 quanta, sorted by height, with 1024 height buckets
+ *                                             vertical strip (2^15..2^17 quanta, by the mean width of a segment), sorted by height, with 1024 height buckets
  *                                             per strip -- a query point scans the entries above it in its own strip
  *                                             (k_pip_strip) instead of walking the tree.  -1 built where most chains are
  *                                             closed rings (lakes, parks: many small isolated faces), 0 never, 1 always.
@@ -340,7 +340,7 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  *
  * rj_get_option reads any of these, and what the handle did or decided:
  *   "leaf_order_used0/1", "leaf_slots0/1", "leaf_runs0/1", "skyline_used0/1", "closed_chains0/1",
- *   "pip_columns_used0/1", "pip_column_entries0/1"              the index of map 0 / 1
+ *   "pip_columns_used0/1", "pip_column_entries0/1", "pip_column_shift0/1"   the index of map 0 / 1
  *   "stitch_rounds", "stitch_loop_ends"                         the last run cutting (pointer-jumping rounds; closed loops)
  *   "pip_schedule" (0 turns, 1 shared, 2 full grids, -1 still trying), "pip_schedule_trials", "pip_schedule_us0/1/2",
  *   "lsi_share_blocks", "pip_share_blocks"                      what "pip_concurrent" 2 measured and settled on
@@ -349,7 +349,7 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 int rj_get_option(rj_handle h, const char* name, int64_t* value);
 /* Experiment knobs for tools/ and the fault-path tests -- grids, chunk sizes, run lengths ("chunk_groups",
- * "group_lanes", "max_blocks", "lsi_share_blocks", "pip_share_blocks", "stack_cap", "walk_stack", "run_cap", "pack_solo",
+ * "group_lanes", "max_blocks", "lsi_share_blocks", "pip_share_blocks", "stack_cap", "walk_stack", "strip_shift", "run_cap", "pack_solo",
  * "pack_spread"; rj_api.hip lists their ranges).  Not needed by a host of the library, never a correctness input,
  * no promise that a name survives a round. */
 int rj_set_debug_option(rj_handle h, const char* name, int64_t value);

@@ -59,7 +59,11 @@ struct BvhState {
   bool use_sky = false;     // ... filled and used (maps of isolated rings)
   // the column index (rj_device.h DeviceStrips; maps of isolated rings): what the PIP query's first pass runs on instead
   // of the tree
-  uint32_t *strip_ytab = nullptr, *strip_slot = nullptr, *strip_tall = nullptr;
+  uint32_t* strip_ytab = nullptr;
+  uint4* strip_info = nullptr;   // [strip_cap] {slot, edge id, face id, 0} per entry
+  uint2* strip_tall = nullptr;   // [strips] {tallest box, end of the strip's entries}
+  int strip_shift = 0;           // a strip is 2^strip_shift quanta wide (chosen by the map's segments, build_strips)
+  int strip_tab_shift = 0;       // ... and the width strip_tall / strip_ytab are allocated for (0: not yet)
   QBox* strip_box = nullptr;
   uint64_t strip_entries = 0, strip_cap = 0;
   bool strips_built = false;
@@ -172,6 +176,7 @@ struct rj_handle_s {
   uint32_t* d_fault = nullptr;              // the same memory as the device sees it
   int debug_stack_cap = 1 << 30;            // tests of the fault path only
   int debug_walk_stack = 0;                 // tests of the groups that leave the walk (0: kWalkStack entries)
+  int debug_strip_shift = 0;                // the column index of the next build on strips of 2^this quanta (0: by the map)
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
@@ -309,7 +314,7 @@ void free_grid(GridState& g) {
 
 void free_bvh(BvhState& b) {
   (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
-  (void) hipFree(b.strip_ytab); (void) hipFree(b.strip_slot); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_box);
+  (void) hipFree(b.strip_ytab); (void) hipFree(b.strip_info); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_box);
   for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
@@ -323,7 +328,7 @@ DeviceBvh bvh_view(const BvhState& b) {
   }
   d.top = b.top; d.n0 = b.n0;
   d.strips.ytab = b.strips_built ? b.strip_ytab : nullptr;
-  d.strips.ebox = b.strip_box; d.strips.eslot = b.strip_slot; d.strips.tall = b.strip_tall;
+  d.strips.ebox = b.strip_box; d.strips.einfo = b.strip_info; d.strips.tall = b.strip_tall; d.strips.shift = b.strip_shift;
   return d;
 }
 
@@ -596,6 +601,7 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_columns")) *value = h->pip_columns;
   else if (!strcmp(name, "pip_columns_used0") || !strcmp(name, "pip_columns_used1")) *value = h->bvh[name[16] - '0'].strips_built ? 1 : 0;
   else if (!strcmp(name, "pip_column_entries0") || !strcmp(name, "pip_column_entries1")) *value = (int64_t) h->bvh[name[18] - '0'].strip_entries;
+  else if (!strcmp(name, "pip_column_shift0") || !strcmp(name, "pip_column_shift1")) *value = h->bvh[name[16] - '0'].strips_built ? h->bvh[name[16] - '0'].strip_shift : 0;
   else if (!strcmp(name, "pip_last_columns")) *value = h->last_columns;
   else if (!strcmp(name, "skyline_used0") || !strcmp(name, "skyline_used1")) *value = h->bvh[name[12] - '0'].use_sky ? 1 : 0;
   else if (!strcmp(name, "closed_chains0") || !strcmp(name, "closed_chains1")) *value = (int64_t) h->map[name[13] - '0'].closed_chains;
@@ -679,6 +685,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
       {"pip_share_blocks", &h->pip_share_set, 0, 1 << 20},
       {"stack_cap", &h->debug_stack_cap, 1, 1 << 30},     // instrumented kernels: fewer traversal-stack entries (fault path)
       {"walk_stack", &h->debug_walk_stack, 0, 1 << 30},   // k_pip_walk*: fewer stack entries (groups that need more leave the walk)
+      {"strip_shift", &h->debug_strip_shift, 0, 20},      // the column index on strips of 2^this quanta (0: chosen by the map; 14..20)
       {"run_cap", &h->debug_run_cap, 0, 64},              // edges per polyline run of the next first build of a map (0: 64)
       {"pack_solo", &h->debug_pack_solo, 0, 64},          // a run longer than this never shares its leaf (0: 48)
       {"pack_spread", &h->debug_pack_spread, 0, 1000000}, // a shared leaf may be this many times as large as its runs (0: 8)
@@ -687,6 +694,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
     if (!strcmp(name, k.name)) {
       if (value < k.lo || value > k.hi) return fail(h, RJ_E_INVALID, "%s: %lld..%lld", name, (long long) k.lo, (long long) k.hi);
       if (!strcmp(name, "run_cap") && value == 1) return fail(h, RJ_E_INVALID, "run_cap: 0 or 2..64");
+      if (!strcmp(name, "strip_shift") && value != 0 && value < 14) return fail(h, RJ_E_INVALID, "strip_shift: 0 or 14..20");
       *k.var = (int) value;
       return RJ_OK;
     }
@@ -709,6 +717,7 @@ int rj_get_debug_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_share_blocks")) *value = h->pip_share_set;
   else if (!strcmp(name, "stack_cap")) *value = h->debug_stack_cap;
   else if (!strcmp(name, "walk_stack")) *value = h->debug_walk_stack;
+  else if (!strcmp(name, "strip_shift")) *value = h->debug_strip_shift;
   else if (!strcmp(name, "run_cap")) *value = h->debug_run_cap;
   else if (!strcmp(name, "pack_solo")) *value = h->debug_pack_solo;
   else if (!strcmp(name, "pack_spread")) *value = h->debug_pack_spread;
@@ -869,27 +878,38 @@ static int build_strips(rj_handle h, BvhState& b) {
     h->strip_scratch_bytes = bytes;
     return RJ_OK;
   };
+  // the strip width: widest power of two below 2.3 x the mean x-extent of a segment (rj_device.h, DeviceStrips)
   size_t scan_bytes = 0;
-  RJ_HIP(h, launch_strip_count(h->stream, nullptr, nullptr, b.n0p, nullptr, nullptr, nullptr, scan_bytes, nullptr));
+  RJ_HIP(h, launch_strip_count(h->stream, nullptr, nullptr, b.n0p, 0, nullptr, nullptr, nullptr, scan_bytes, nullptr));
   const size_t cnt_bytes = up(4 * (b.n0p + 1));
   // pass 1 needs: cnt, offs, flag, scan temp; pass 2 adds key_tmp, slot_tmp, sort temp (sized once the total is known:
   // an upper bound first -- twice the slots covers every map whose segments are not wider than a strip or two)
   if (int r = scratch(2 * cnt_bytes + 256 + up(scan_bytes))) return r;
+  RJ_HIP(h, launch_strip_width(h->stream, b.box0, b.seid, b.n0p, (unsigned long long*) h->strip_scratch));
+  RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 30, h->strip_scratch, 16, hipMemcpyDeviceToHost, h->stream));
+  RJ_HIP(h, hipStreamSynchronize(h->stream));
+  if (!h->h_pinned[31]) return RJ_OK;  // (no real segment)
+  const double mean_dx = (double) h->h_pinned[30] / (double) h->h_pinned[31];
+  int shift = kStripShiftMin;
+  while (shift < kStripShiftMax && (double) (2u << shift) <= 2.3 * mean_dx) shift++;
+  if (h->debug_strip_shift) shift = h->debug_strip_shift;
+  const uint32_t strips = strip_count(shift);
   uint32_t* cnt = (uint32_t*) h->strip_scratch;
   uint32_t* offs = (uint32_t*) (h->strip_scratch + cnt_bytes);
   uint32_t* flag = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes);
   void* temp = h->strip_scratch + 2 * cnt_bytes + 256;
   RJ_HIP(h, hipMemsetAsync(flag, 0, 4, h->stream));
   size_t tb = scan_bytes;
-  RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, cnt, offs, temp, tb, flag));
+  RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, shift, cnt, offs, temp, tb, flag));
   RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 30, offs + b.n0p, 4, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipMemcpyAsync((uint32_t*) (h->h_pinned + 30) + 1, flag, 4, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   const uint32_t total = (uint32_t) h->h_pinned[30], bad = (uint32_t) (h->h_pinned[30] >> 32);
   if (bad || total == 0) return RJ_OK;  // (a segment spanning more than kStripMaxSpan strips: the tree alone serves this map)
   size_t sort_bytes = 0;
-  RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, b.n0p, total, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
-  const size_t need = 2 * cnt_bytes + 256 + 2 * up(8 * (size_t) total) + up(4 * (size_t) total) + up(sort_bytes);
+  RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, b.n0p, shift, total, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
+  const size_t need = 2 * cnt_bytes + 256 + 2 * up(8 * (size_t) total) + 2 * up(4 * (size_t) total) + up(4 * (size_t) strips) + up(sort_bytes);
   if (need > h->strip_scratch_bytes) {
     // (the counts live in the scratch block that is about to move: count again into the new one -- first build of a
     //  larger map only)
@@ -897,27 +917,33 @@ static int build_strips(rj_handle h, BvhState& b) {
     cnt = (uint32_t*) h->strip_scratch; offs = (uint32_t*) (h->strip_scratch + cnt_bytes); flag = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes);
     temp = h->strip_scratch + 2 * cnt_bytes + 256;
     tb = scan_bytes;
-    RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, cnt, offs, temp, tb, flag));
+    RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, shift, cnt, offs, temp, tb, flag));
   }
   uint64_t* key_tmp = (uint64_t*) (h->strip_scratch + 2 * cnt_bytes + 256);
   uint64_t* key = (uint64_t*) ((char*) key_tmp + up(8 * (size_t) total));
   uint32_t* slot_tmp = (uint32_t*) ((char*) key + up(8 * (size_t) total));
-  temp = (char*) slot_tmp + up(4 * (size_t) total);
+  uint32_t* slot_sorted = (uint32_t*) ((char*) slot_tmp + up(4 * (size_t) total));
+  uint32_t* tall_tmp = (uint32_t*) ((char*) slot_sorted + up(4 * (size_t) total));
+  temp = (char*) tall_tmp + up(4 * (size_t) strips);
   if (b.strip_cap < total) {
-    (void) hipFree(b.strip_slot); (void) hipFree(b.strip_box);
-    b.strip_slot = nullptr; b.strip_box = nullptr; b.strip_cap = 0;
+    (void) hipFree(b.strip_info); (void) hipFree(b.strip_box);
+    b.strip_info = nullptr; b.strip_box = nullptr; b.strip_cap = 0;
     const uint64_t cap = (uint64_t) total + total / 16;
     if (int r = dev_alloc(h, &b.strip_box, cap)) return r;
-    if (int r = dev_alloc(h, &b.strip_slot, cap)) return r;
+    if (int r = dev_alloc(h, &b.strip_info, cap)) return r;
     b.strip_cap = cap;
   }
-  if (!b.strip_tall) {
-    if (int r = dev_alloc(h, &b.strip_tall, (uint64_t) kStrips)) return r;
-    if (int r = dev_alloc(h, &b.strip_ytab, ((uint64_t) kStrips << kStripYBits) + 1)) return r;
+  if (!b.strip_tall || b.strip_tab_shift > shift) {  // (narrower strips than the tables were made for)
+    (void) hipFree(b.strip_tall); (void) hipFree(b.strip_ytab);
+    b.strip_tall = nullptr; b.strip_ytab = nullptr; b.strip_tab_shift = 0;
+    if (int r = dev_alloc(h, &b.strip_tall, (uint64_t) strips)) return r;
+    if (int r = dev_alloc(h, &b.strip_ytab, ((uint64_t) strips << kStripYBits) + 1)) return r;
+    b.strip_tab_shift = shift;
   }
   tb = sort_bytes;
-  RJ_HIP(h, launch_strip_fill(h->stream, b.box0, cnt, offs, b.n0p, total, key, b.strip_slot, key_tmp, slot_tmp, b.strip_tall,
-                              b.strip_ytab, b.strip_box, temp, tb));
+  RJ_HIP(h, launch_strip_fill(h->stream, b.box0, b.seid, b.sface, cnt, offs, b.n0p, shift, total, key, slot_sorted, key_tmp, slot_tmp, tall_tmp,
+                              b.strip_ytab, b.strip_box, b.strip_info, b.strip_tall, temp, tb));
+  b.strip_shift = shift;
   b.strip_entries = total;
   b.strips_built = true;
   return RJ_OK;

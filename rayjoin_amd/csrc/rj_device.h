@@ -80,22 +80,28 @@ struct DeviceMap {
 };
 
 // The COLUMN index of an indexed map (round 4, maps of isolated rings): the domain cut into vertical strips of
-// 2^kStripShift quanta; per strip the boxes of the sorted slots that touch it, ascending by y0, and a table of where
+// 2^shift quanta; per strip the boxes of the sorted slots that touch it, ascending by y0, and a table of where
 // every one of 1024 height buckets starts in that list.  An upward ray lives in ONE strip: one table read finds the
 // entries at its height, a short scan upwards finds the edges above it -- O(1) per point wherever the point lies, where
 // the box hierarchy opens every leaf block over the column whose x-extent contains the point (20 per point on the
 // lake-shaped stand-in, 19 of them with nothing at that x).  The walk's job on such maps, with the walk's hand-over
 // (k_pip_strip, rj_strip.hip).
-constexpr int kStripShift = 16;
-constexpr int kStrips = 1 << (31 - kStripShift);  // 32 768
+// The strip width follows the map: what a point's scan wastes is entries that lie in its strip BESIDE it (5.0 of the
+// 6.6 entries a point of the lake-shaped pair reads, 8.1 of 10.5 on lakes x parks), fewer the narrower the strip, while
+// every strip a segment touches is one more entry.  Widest power of two below 2.3 x the mean x-extent of a segment,
+// within [2^15, 2^17] (measured at 2^14 / 2^15 / 2^16, first pass: lake-shaped 2.55 / 2.19 / 2.13 ms, lakes x parks
+// 2.08 / 1.98 / 3.72, gaussian polygons 0.84 / 0.63 / 0.67).
+constexpr int kStripShiftMin = 15, kStripShiftMax = 17;
 constexpr int kStripYBits = 10;                   // height buckets per strip: 1024 of 2^21 quanta (256: 2.42 / 3.98 / 1.10 ms first pass on the three ring pairs; 1024: 2.26 / 3.89 / 0.72; 2048: 2.27 / 3.91 / 0.66 at twice the table)
 constexpr int kStripYShift = 31 - kStripYBits;
 constexpr int kStripMaxSpan = 1024;               // strips one segment may touch (more: the index is not built)
+__host__ __device__ __forceinline__ uint32_t strip_count(int shift) { return 1u << (31 - shift); }
 struct DeviceStrips {
-  const uint32_t* ytab;   // [kStrips * 1024 + 1] first entry at or above (strip, height bucket); nullptr: no index
+  const uint32_t* ytab;   // [strips * 1024 + 1] first entry at or above (strip, height bucket); nullptr: no index
   const QBox* ebox;       // [entries] the slot's box, entries ascending by (strip, y0)
-  const uint32_t* eslot;  // [entries] the sorted slot (seid / sface index)
-  const uint32_t* tall;   // [kStrips] largest box height (y1 - y0) among the strip's entries
+  const uint4* einfo;     // [entries] {sorted slot, its edge id, its face id, 0}: what a candidate and a settled point need, one line
+  const uint2* tall;      // [strips] {largest box height (y1 - y0) among the strip's entries, where the strip's entries end}
+  int shift;              // a strip is 2^shift quanta wide
 };
 
 struct DeviceBvh {

@@ -125,11 +125,13 @@ hipError_t warm_stitch_kernels(hipStream_t st);
 hipError_t warm_strip_kernels(hipStream_t st);
 // The column index of an indexed map (rj_strip.hip, rj_device.h DeviceStrips) and the PIP pass on it.  Both build passes
 // answer a call with temp == nullptr with the temporary bytes they need.
-hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* cnt, uint32_t* offs,
+hipError_t launch_strip_width(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, unsigned long long* out2);
+hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, int shift, uint32_t* cnt, uint32_t* offs,
                               void* temp, size_t& temp_bytes, uint32_t* flag);
-hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* cnt, const uint32_t* offs, uint64_t n0p, uint64_t entries,
-                             uint64_t* key, uint32_t* eslot, uint64_t* key_tmp, uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab,
-                             QBox* ebox, void* temp, size_t& temp_bytes);
+hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* seid, const int32_t* sface, const uint32_t* cnt,
+                             const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint64_t* key, uint32_t* eslot, uint64_t* key_tmp,
+                             uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, void* temp,
+                             size_t& temp_bytes);
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus);
 // Polyline runs of a map, cut on the device (rj_stitch.hip): pieces and runs into caller-owned arrays sized by
 // stitch_output_bounds; two host syncs (closed loops left? -- the totals), no read-back of the map.

@@ -32,25 +32,25 @@ inline int blocks_for(uint64_t n, int per_block = 256, int cap = 16384) {
 
 // how many strips the box of sorted slot i touches (0: a padding slot); flag[0] = 1 when one is too wide to register
 __global__ __launch_bounds__(256) void k_strip_count(const QBox* __restrict__ box0, const uint32_t* __restrict__ seid, uint64_t n0p,
-                                                     uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+                                                     int shift, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
   RJ_GRID_STRIDE(i, n0p) {
     uint32_t c = 0;
     if (seid[i] != 0xFFFFFFFFu) {
       const QBox b = box0[i];
-      c = (uint32_t) ((b.x1 >> kStripShift) - (b.x0 >> kStripShift) + 1);
+      c = (uint32_t) ((b.x1 >> shift) - (b.x0 >> shift) + 1);
       if (c > (uint32_t) kStripMaxSpan) { c = 0; flag[0] = 1u; }
     }
     cnt[i] = c;
   }
 }
 __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box0, const uint32_t* __restrict__ cnt,
-                                                    const uint32_t* __restrict__ offs, uint64_t n0p, uint64_t* __restrict__ key,
+                                                    const uint32_t* __restrict__ offs, uint64_t n0p, int shift, uint64_t* __restrict__ key,
                                                     uint32_t* __restrict__ slot, uint32_t* __restrict__ tall) {
   RJ_GRID_STRIDE(i, n0p) {
     const uint32_t c = cnt[i];
     if (!c) continue;
     const QBox b = box0[i];
-    const uint32_t s0 = (uint32_t) (b.x0 >> kStripShift), h = (uint32_t) (b.y1 - b.y0);
+    const uint32_t s0 = (uint32_t) (b.x0 >> shift), h = (uint32_t) (b.y1 - b.y0);
     const uint32_t o = offs[i];
     for (uint32_t k = 0; k < c; k++) {
       key[o + k] = ((uint64_t) (s0 + k) << 32) | (uint32_t) b.y0;
@@ -68,13 +68,36 @@ __device__ __forceinline__ uint32_t strip_bucket(uint64_t key) {
   return ((uint32_t) (key >> 32) << kStripYBits) | ((uint32_t) key >> kStripYShift);
 }
 __global__ __launch_bounds__(256) void k_strip_finish(const uint64_t* __restrict__ key, const uint32_t* __restrict__ slot, uint64_t n,
-                                                      const QBox* __restrict__ box0, QBox* __restrict__ ebox, uint32_t* __restrict__ ytab) {
+                                                      const QBox* __restrict__ box0, const uint32_t* __restrict__ seid,
+                                                      const int32_t* __restrict__ sface, QBox* __restrict__ ebox,
+                                                      uint4* __restrict__ einfo, uint32_t* __restrict__ ytab, uint32_t strips) {
   RJ_GRID_STRIDE(j, n) {
-    ebox[j] = box0[slot[j]];
+    const uint32_t sl = slot[j];
+    ebox[j] = box0[sl];
+    einfo[j] = make_uint4(sl, seid[sl], (uint32_t) sface[sl], 0u);
     const uint32_t g = strip_bucket(key[j]);
     if (j == 0 || strip_bucket(key[j - 1]) != g) ytab[g] = (uint32_t) j;
-    if (j == n - 1) ytab[(uint32_t) kStrips << kStripYBits] = (uint32_t) n;
+    if (j == n - 1) ytab[strips << kStripYBits] = (uint32_t) n;
   }
+}
+
+// every strip's tallest box and, beside it, where its entries end (the table entry of the next strip's first bucket,
+// after the suffix minimum): one 8-byte read per query point instead of two lines
+__global__ __launch_bounds__(256) void k_strip_ends(const uint32_t* __restrict__ tall, const uint32_t* __restrict__ ytab, uint32_t strips,
+                                                    uint2* __restrict__ out) {
+  RJ_GRID_STRIDE(s, (uint64_t) strips) out[s] = make_uint2(tall[s], ytab[(s + 1) << kStripYBits]);
+}
+// the sum of the x-extents of every 8th real segment, and how many were summed (out[0], out[1]): what the strip width
+// is chosen by
+__global__ __launch_bounds__(256) void k_strip_width(const QBox* __restrict__ box0, const uint32_t* __restrict__ seid, uint64_t n0p,
+                                                     unsigned long long* __restrict__ out) {
+  unsigned long long w = 0, c = 0;
+  RJ_GRID_STRIDE(i, (n0p + 7) / 8) {
+    const uint64_t k = i * 8;
+    if (seid[k] != 0xFFFFFFFFu) { const QBox b = box0[k]; w += (unsigned long long) (b.x1 - b.x0); c++; }
+  }
+  for (int o = 32; o > 0; o >>= 1) { w += __shfl_down(w, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63) == 0 && c) { atomicAdd(&out[0], w); atomicAdd(&out[1], c); }
 }
 
 // PTS query points per lane: a wave takes PTS x 64 consecutive positions (point set p = positions 64 p + lane of the
@@ -100,6 +123,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     bool valid[PTS];
     uint32_t ip[PTS], j[PTS], jend[PTS], cand_base[PTS], cand_at[PTS];
     int32_t qx[PTS], qy[PTS], qym1[PTS], qbest[PTS], sure_y0[PTS];
+    uint32_t sure_j[PTS];  // the entry of the one certain hit a list holds (valid where sure_y0 is)
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
       const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
@@ -117,6 +141,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
       cand_at[p] = cand_base[p];
       sure_y0[p] = INT32_MIN;
+      sure_j[p] = 0;
       j[p] = jend[p] = 0;
     }
     // the strip's entries from the height bucket of the lowest y0 that can still reach up to the point
@@ -127,11 +152,12 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
       if (valid[p] && ray_has_sky(sky, qx[p], qy[p])) {  // (above the map's skyline: a certain miss)
-        const uint32_t s = (uint32_t) qx[p] >> kStripShift;
-        const int64_t from = (int64_t) qym1[p] - (int64_t) S.tall[s];
+        const uint32_t s = (uint32_t) qx[p] >> S.shift;
+        const uint2 te = S.tall[s];
+        const int64_t from = (int64_t) qym1[p] - (int64_t) te.x;
         const uint32_t want = from > 0 ? (uint32_t) from : 0u;
         j[p] = S.ytab[(s << kStripYBits) | (want >> kStripYShift)];
-        jend[p] = S.ytab[(s + 1) << kStripYBits];
+        jend[p] = te.y;
       }
     }
     for (;;) {
@@ -147,13 +173,14 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
         if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p])) >= 0) {
           // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
           // ends below the start of the one certain hit held so far replaces it
-          const uint32_t slot = S.eslot[j[p]];
+          const uint32_t slot = S.einfo[j[p]].x;
           const bool certain = b[p].x0 < qx[p] && qx[p] < b[p].x1 && b[p].y0 > qy[p];
           const bool replace = certain && b[p].y1 < sure_y0[p];
           const bool first = cand_at[p] == cand_base[p];
           const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
           cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot;
           sure_y0[p] = (replace || (first && certain)) ? b[p].y0 : INT32_MIN;
+          sure_j[p] = (replace || (first && certain)) ? j[p] : sure_j[p];
           cand_at[p] += replace ? 0u : 64u;
           const int32_t top = certain ? b[p].y1 + 1 : 0x7FFFFFFF;
           qbest[p] = over ? -1 : (top < qbest[p] ? top : qbest[p]);
@@ -169,10 +196,12 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
       const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
       if (done) {
+        // (the hit's edge and face ids sit beside the slot its candidate was read from: the line is in the cache)
         const bool hit = cand_at[p] != cand_base[p];
-        const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
-        __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip[p]);
-        if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip[p]);
+        uint4 inf = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
+        if (hit) inf = S.einfo[sure_j[p]];
+        __builtin_nontemporal_store(inf.y, A.closest + ip[p]);
+        if (A.face) __builtin_nontemporal_store((int32_t) inf.z, A.face + ip[p]);
       }
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
       const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
@@ -207,21 +236,29 @@ hipError_t warm_strip_kernels(hipStream_t st) {
 
 // pass 1 of the build: per-slot strip counts and their exclusive scan (cnt, offs: n0p + 1 words each); *total_out on
 // the stream (mapped or device memory), flag[0] = 1 when the index cannot be built
-hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* cnt, uint32_t* offs,
+hipError_t launch_strip_width(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, unsigned long long* out2) {
+  hipError_t e = hipMemsetAsync(out2, 0, 16, st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_strip_width, dim3(blocks_for((n0p + 7) / 8, 256, 2048)), dim3(256), 0, st, box0, seid, n0p, out2);
+  return hipGetLastError();
+}
+hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, int shift, uint32_t* cnt, uint32_t* offs,
                               void* temp, size_t& temp_bytes, uint32_t* flag) {
   if (!temp) return rocprim::exclusive_scan(nullptr, temp_bytes, (const uint32_t*) nullptr, (uint32_t*) nullptr, 0u, (size_t) n0p + 1,
                                             rocprim::plus<uint32_t>(), st);
   hipError_t e = hipMemsetAsync(cnt + n0p, 0, 4, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_count, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, seid, n0p, cnt, flag);
+  hipLaunchKernelGGL(k_strip_count, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, seid, n0p, shift, cnt, flag);
   return rocprim::exclusive_scan(temp, temp_bytes, cnt, offs, 0u, (size_t) n0p + 1, rocprim::plus<uint32_t>(), st);  // offs[n0p] = the total
 }
-// pass 2: the entries, sorted by (strip, y0), with their boxes and the height-bucket table; key / key_tmp / slot_tmp:
-// temporaries of `entries` elements; tall[kStrips] zeroed here
-hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* cnt, const uint32_t* offs, uint64_t n0p, uint64_t entries,
-                             uint64_t* key, uint32_t* eslot, uint64_t* key_tmp, uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab,
-                             QBox* ebox, void* temp, size_t& temp_bytes) {
-  const unsigned bits = 32 + (31 - kStripShift);
+// pass 2: the entries, sorted by (strip, y0), with their boxes, their {slot, edge id, face id} and the height-bucket
+// table; key / eslot / key_tmp / slot_tmp: temporaries of `entries` elements; tall[strips] (temporary) zeroed here
+hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* seid, const int32_t* sface, const uint32_t* cnt,
+                             const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint64_t* key, uint32_t* eslot, uint64_t* key_tmp,
+                             uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, void* temp,
+                             size_t& temp_bytes) {
+  const unsigned bits = 32 + (31 - shift);
+  const uint32_t strips = strip_count(shift);
   if (!temp) {
     size_t a = 0, b = 0;
     hipError_t q = rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*) nullptr, (uint64_t*) nullptr, (const uint32_t*) nullptr,
@@ -229,23 +266,25 @@ hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* c
     if (q != hipSuccess) return q;
     uint32_t* z = nullptr;
     auto rz = rocprim::make_reverse_iterator(z);
-    q = rocprim::inclusive_scan(nullptr, b, rz, rz, ((size_t) kStrips << kStripYBits) + 1, rocprim::minimum<uint32_t>(), st);
+    q = rocprim::inclusive_scan(nullptr, b, rz, rz, ((size_t) strips << kStripYBits) + 1, rocprim::minimum<uint32_t>(), st);
     temp_bytes = a > b ? a : b;
     return q;
   }
-  hipError_t e = hipMemsetAsync(tall, 0, (size_t) kStrips * 4, st);
+  hipError_t e = hipMemsetAsync(tall, 0, (size_t) strips * 4, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_emit, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, cnt, offs, n0p, key_tmp, slot_tmp, tall);
+  hipLaunchKernelGGL(k_strip_emit, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, cnt, offs, n0p, shift, key_tmp, slot_tmp, tall);
   if ((e = rocprim::radix_sort_pairs(temp, temp_bytes, key_tmp, key, slot_tmp, eslot, (size_t) entries, 0, bits, st)) != hipSuccess) return e;
-  const size_t nt = ((size_t) kStrips << kStripYBits) + 1;
+  const size_t nt = ((size_t) strips << kStripYBits) + 1;
   if ((e = hipMemsetAsync(ytab, 0xFF, nt * 4, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_finish, dim3(blocks_for(entries)), dim3(256), 0, st, key, eslot, entries, box0, ebox, ytab);
+  hipLaunchKernelGGL(k_strip_finish, dim3(blocks_for(entries)), dim3(256), 0, st, key, eslot, entries, box0, seid, sface, ebox, einfo, ytab, strips);
   // suffix minimum, in place (the sort's temporary storage is free again and larger than a scan's)
   size_t need = 0;
   auto rb = rocprim::make_reverse_iterator(ytab + nt);
   if ((e = rocprim::inclusive_scan(nullptr, need, rb, rb, nt, rocprim::minimum<uint32_t>(), st)) != hipSuccess) return e;
   if (need > temp_bytes) return hipErrorInvalidValue;
-  return rocprim::inclusive_scan(temp, need, rb, rb, nt, rocprim::minimum<uint32_t>(), st);
+  if ((e = rocprim::inclusive_scan(temp, need, rb, rb, nt, rocprim::minimum<uint32_t>(), st)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_strip_ends, dim3(blocks_for(strips)), dim3(256), 0, st, tall, ytab, strips, tall_end);
+  return hipGetLastError();
 }
 
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus) {

@@ -115,3 +115,38 @@ def test_columns_beside_an_lsi_query(oracle):
                 assert np.array_equal(faces.to_host(np.int32), m0.face_ids(want_e)), (conc, rep)
     finally:
         h.close()
+
+
+def test_the_strip_width_follows_the_map_and_never_changes_an_answer(oracle):
+    """The strips are as wide as the map's segments ask (rj_device.h DeviceStrips: widest power of two below 2.3 x their
+    mean x-extent, within 2^15..2^17 quanta); "strip_shift" (an experiment knob) forces a width.  Every width answers
+    alike -- narrower strips register a segment more often, wider ones scan more entries beside the point -- and a
+    rebuild on narrower strips than the tables were made for allocates them again."""
+    ctx = maps.Context([synth.ring_map(6000, 70000, 3), synth.lattice_map(40, 25, 6)]).load()
+    b, q = ctx.maps
+    m0 = _omap(oracle, b)
+    want = oracle.pip_grid(m0, 0, q.pts, 256)
+    h = _capi.Handle(0)
+    try:
+        h.upload_map(0, b.pts, b.row_index, b.left, b.right)
+        h.upload_map(1, q.pts, q.row_index, q.left, q.right)
+        closest, faces = h.alloc(4 * q.n_points), h.alloc(4 * q.n_points)
+        h.build_lbvh(0)
+        assert h.get_option("pip_columns_used0") == 1
+        auto = h.get_option("pip_column_shift0")
+        assert 15 <= auto <= 17       # (6000 rings over the whole domain: long segments, the widest strips)
+        entries = {}
+        for shift in (17, 20, 15, 14, 16, 0):
+            h.set_debug_option("strip_shift", shift)
+            h.build_lbvh(0)
+            assert h.get_option("pip_columns_used0") == 1
+            assert h.get_option("pip_column_shift0") == (shift or auto)
+            entries[shift] = h.get_option("pip_column_entries0")
+            e, f = _pip(h, 0, None, q.n_points, closest, faces)
+            assert h.get_option("pip_last_columns") == 1
+            assert np.array_equal(e, want), shift
+            assert np.array_equal(f, m0.face_ids(want)), shift
+        assert entries[14] > entries[15] > entries[16] > entries[17] > entries[20]
+        assert entries[0] == entries[auto]
+    finally:
+        h.close()
