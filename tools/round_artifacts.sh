@@ -35,5 +35,6 @@ echo "leaf order done"
 timeout -k 10 200 python3 tools/schedule_probe.py --steps 8 2>/dev/null | grep "^{" > gpurun_out/${TAG}_schedule_probe.txt
 timeout -k 10 400 python3 tools/build_probe.py --maps USCounty,BlockGroup,WaterBodies,LakesNA,WaterBodiesLike,LakesLike 2>/dev/null | tail -12 > gpurun_out/${TAG}_build_probe.txt
 timeout -k 10 300 python3 tools/ring_stats_probe.py 2>/dev/null > gpurun_out/${TAG}_ring_stats.txt
+timeout -k 10 500 python3 tools/stack_depth_probe.py 2>/dev/null > gpurun_out/${TAG}_stack_depth.txt
 fi
 echo "all done"
