@@ -1499,7 +1499,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // (a base map with a column index answers every point on its own -- nothing is shared between the points of a wave,
   //  so a scattered query set needs no re-ordering there)
   const bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && !h->stats_on;
-  if (by_columns) { h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr; }
+  if (by_columns && h->query_order != 2) { h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr; }
   else if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
   // "pip_concurrent": the kernel goes to the handle's second stream and runs BESIDE the LSI kernel
   // of the same step on the main stream (both only read the maps and the tree): with an LSI query in

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     bool valid[PTS];
     uint32_t ip[PTS], j[PTS], jend[PTS], cand_base[PTS], cand_at[PTS];
     int32_t qx[PTS], qy[PTS], qym1[PTS], qbest[PTS], sure_y0[PTS];
-    uint32_t sure_j[PTS];  // the entry of the one certain hit a list holds (valid where sure_y0 is)
+    uint32_t sure_eid[PTS], sure_face[PTS];  // edge and face of the one certain hit a list holds (valid where sure_y0 is)
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
       const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
       cand_at[p] = cand_base[p];
       sure_y0[p] = INT32_MIN;
-      sure_j[p] = 0;
+      sure_eid[p] = 0xFFFFFFFFu; sure_face[p] = 0;
       j[p] = jend[p] = 0;
     }
     // the strip's entries from the height bucket of the lowest y0 that can still reach up to the point
@@ -173,14 +173,16 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
         if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p])) >= 0) {
           // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
           // ends below the start of the one certain hit held so far replaces it
-          const uint32_t slot = S.einfo[j[p]].x;
+          const uint4 inf = S.einfo[j[p]];  // {slot, edge id, face id}: one 16-byte read
+          const uint32_t slot = inf.x;
           const bool certain = b[p].x0 < qx[p] && qx[p] < b[p].x1 && b[p].y0 > qy[p];
           const bool replace = certain && b[p].y1 < sure_y0[p];
           const bool first = cand_at[p] == cand_base[p];
           const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
           cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot;
           sure_y0[p] = (replace || (first && certain)) ? b[p].y0 : INT32_MIN;
-          sure_j[p] = (replace || (first && certain)) ? j[p] : sure_j[p];
+          sure_eid[p] = (replace || (first && certain)) ? inf.y : sure_eid[p];
+          sure_face[p] = (replace || (first && certain)) ? inf.z : sure_face[p];
           cand_at[p] += replace ? 0u : 64u;
           const int32_t top = certain ? b[p].y1 + 1 : 0x7FFFFFFF;
           qbest[p] = over ? -1 : (top < qbest[p] ? top : qbest[p]);
@@ -196,12 +198,10 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
       const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
       if (done) {
-        // (the hit's edge and face ids sit beside the slot its candidate was read from: the line is in the cache)
+        // (the hit's edge and face ids came with the slot its candidate was read from: no further read)
         const bool hit = cand_at[p] != cand_base[p];
-        uint4 inf = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
-        if (hit) inf = S.einfo[sure_j[p]];
-        __builtin_nontemporal_store(inf.y, A.closest + ip[p]);
-        if (A.face) __builtin_nontemporal_store((int32_t) inf.z, A.face + ip[p]);
+        __builtin_nontemporal_store(hit ? sure_eid[p] : 0xFFFFFFFFu, A.closest + ip[p]);
+        if (A.face) __builtin_nontemporal_store(hit ? (int32_t) sure_face[p] : 0, A.face + ip[p]);
       }
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
       const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
