@@ -61,8 +61,9 @@ struct PipArgs {
   int walk_stack;        // k_pip_walk*: use fewer than kWalkStack entries (0: all; tests of the groups that leave the walk)
   unsigned long long* stats;
   // k_pip_walk hand-over.  A point the walk could not settle with integer tests alone leaves its complete candidate
-  // list in `todo` (one 16-byte slot per query POSITION, a 64-bit mask per group says which are filled: no atomics,
-  // no capacity to run out of) and k_pip_exact evaluates it, no traversal; a point whose list overflowed goes to
+  // list in `todo` (room for one 24-byte record per query position; a group's records lie side by side at the head of
+  // the group's region, in the order of the bits of its 64-bit mask: no atomics, no capacity to run out of, and a
+  // group with a dozen listed points is three lines) and k_pip_exact evaluates it, no traversal; a point whose list overflowed goes to
   // `rest` and k_pip locates it from scratch (order = rest, n_dev = the count as the walk left it on the device).
   uint32_t* todo;                        // [n][pip_walk_list_slots()] sorted slots of the index, 0xFFFFFFFF = unused (walk, k_pip_exact)
   unsigned long long* todo_mask;         // [groups] (walk, k_pip_exact)

@@ -1791,11 +1791,14 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     const uint32_t fill = (cand_at - cand_base) >> 6;
     const bool listed = valid && !done && !ovf && fill <= (uint32_t) kWalkList;
     const bool rest = valid && !done && !listed;
-    if (listed) {
-#pragma unroll
-      for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[lane + 64 * k] : 0xFFFFFFFFu;
-    }
+    // (the group's records lie side by side at the head of its todo region, in the order of the mask's bits: a group
+    //  with a dozen listed points writes -- and k_pip_exact reads -- three lines, not a dozen)
     const uint64_t lm = __ballot(listed);
+    if (listed) {
+      const uint64_t rec = (uint64_t) g32 * GL + rank_below(lm);
+#pragma unroll
+      for (int k = 0; k < kWalkList; k++) A.todo[rec * kWalkList + k] = (uint32_t) k < fill ? cand[lane + 64 * k] : 0xFFFFFFFFu;
+    }
     if (lane == 0) A.todo_mask[g32] = lm;
     const uint64_t rm = __ballot(rest);
     if (rm) {
@@ -2036,12 +2039,13 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
       const bool listed = valid[p] && !done && !ovf && fill <= (uint32_t) kWalkList;
       const bool rest = valid[p] && !done && !listed;
-      if (listed) {
-#pragma unroll
-        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
-      }
       const uint64_t lm = __ballot(listed);
       const uint64_t g64 = (uint64_t) g32 * 2 + p;  // the 64-position group this set is
+      if (listed) {
+        const uint64_t rec = g64 * 64 + rank_below(lm);  // (records side by side at the head of the group's region: k_pip_walk)
+#pragma unroll
+        for (int k = 0; k < kWalkList; k++) A.todo[rec * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
+      }
       if (lane == 0 && g64 * 64 < A.n) A.todo_mask[g64] = lm;
       const uint64_t rm = __ballot(rest);
       if (rm) {
@@ -2074,18 +2078,19 @@ __global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A, Pi
     pip_locate<false>(A, blockIdx.x, R, nullptr);
     return;
   }
-  __shared__ uint32_t queue[4][128];
+  __shared__ uint32_t queue[4][128];   // query positions ...
+  __shared__ uint32_t qrec[4][128];    // ... and where their records lie (group base + rank among the group's listed points)
   const DeviceBvh& T = A.bvh;
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
   const uint32_t gl_shift = 31 - __builtin_clz(A.group_lanes);  // (group_lanes is a power of two)
   const uint64_t wave = ((blockIdx.x - R.blocks) * (uint64_t) blockDim.x + threadIdx.x) >> 6;
   const uint64_t nwaves = ((uint64_t) (gridDim.x - R.blocks) * blockDim.x) >> 6;
-  auto evaluate = [&](uint32_t i) {
+  auto evaluate = [&](uint32_t i, uint32_t rec) {
     const uint64_t ip = A.order ? A.order[i] : i;
     uint32_t slot[kWalkList];
 #pragma unroll
-    for (int r = 0; r < kWalkList; r++) slot[r] = A.todo[(uint64_t) i * kWalkList + r];  // (one round trip for the record)
+    for (int r = 0; r < kWalkList; r++) slot[r] = A.todo[(uint64_t) rec * kWalkList + r];  // (one round trip for the record)
     typedef long long ll2_t __attribute__((ext_vector_type(2)));
     const ll2_t pxy = reinterpret_cast<const ll2_t*>(A.pts)[ip];  // (one 16-byte request)
     const int64_t px = pxy.x, py = pxy.y;
@@ -2151,17 +2156,21 @@ __global__ __launch_bounds__(256, RJ_EXACT_WAVES) void k_pip_exact(PipArgs A, Pi
       any &= any - 1;
       const uint64_t m = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (mine >> 32), k) << 32) |
                          (uint32_t) __builtin_amdgcn_readlane((int) mine, k);
-      if ((m >> lane) & 1) queue[wib][nq + rank_below(m)] = (uint32_t) (((g0 + k) << gl_shift) + lane);
+      if ((m >> lane) & 1) {
+        const uint32_t r = rank_below(m);
+        queue[wib][nq + r] = (uint32_t) (((g0 + k) << gl_shift) + lane);
+        qrec[wib][nq + r] = (uint32_t) ((g0 + k) << gl_shift) + r;
+      }
       nq += __popcll(m);
       wave_lds_fence();
       if (nq >= 64) {
-        evaluate(queue[wib][nq - 64 + lane]);
+        evaluate(queue[wib][nq - 64 + lane], qrec[wib][nq - 64 + lane]);
         nq -= 64;
         wave_lds_fence();
       }
     }
   }
-  if (lane < nq) evaluate(queue[wib][lane]);
+  if (lane < nq) evaluate(queue[wib][lane], qrec[wib][lane]);
 }
 
 // =============================================================================================

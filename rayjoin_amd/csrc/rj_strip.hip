@@ -195,7 +195,6 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     // hand-over, per point set: exactly k_pip_walk's
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
-      const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
       const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
       if (done) {
         // (the hit's edge and face ids came with the slot its candidate was read from: no further read)
@@ -206,12 +205,13 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
       const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
       const bool rest = valid[p] && !done && !listed;
-      if (listed) {
-#pragma unroll
-        for (int k = 0; k < kWalkList; k++) A.todo[ipos * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
-      }
       const uint64_t lm = __ballot(listed);
       const uint64_t g64 = g * PTS + p;  // the 64-position group this set is
+      if (listed) {
+        const uint64_t rec = g64 * 64 + rank_below(lm);  // (records side by side at the head of the group's region: k_pip_walk)
+#pragma unroll
+        for (int k = 0; k < kWalkList; k++) A.todo[rec * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
+      }
       if (lane == 0 && g64 * 64 < A.n) A.todo_mask[g64] = lm;
       const uint64_t rm = __ballot(rest);
       if (rm) {
