@@ -1866,21 +1866,20 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
     uint32_t g32 = 0;
     if (!next_group<4>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
     typedef long long ll2_t __attribute__((ext_vector_type(2)));
-    int32_t qx[2], qy[2], qym1[2], qbest[2], sure_y0[2];
-    uint32_t cand_base[2], cand_at[2], ip[2];
+    int32_t qx[2], qy[2], qbest[2], sure_y0[2];
+    uint32_t cand_base[2], cand_at[2];
     bool valid[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
       valid[p] = ipos < A.n;
-      ip[p] = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
+      const uint32_t ip = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
       qx[p] = 0; qy[p] = 0;
       if (valid[p]) {
-        const ll2_t pt = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip[p]);
+        const ll2_t pt = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip);
         qx[p] = quant(pt.x);
         qy[p] = quant(pt.y);
       }
-      qym1[p] = qy[p] > 0 ? qy[p] - 1 : 0;
       qbest[p] = valid[p] ? 0x7FFFFFFF : -1;
       cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
       cand_at[p] = cand_base[p];
@@ -1911,7 +1910,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         um &= um - 1;
         const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        if (__ballot(ray_can_hit(qx[0], qym1[0], qbest[0], cx0, cy0, cx1, cy1) || ray_can_hit(qx[1], qym1[1], qbest[1], cx0, cy0, cx1, cy1)))
+        if (__ballot(ray_can_hit(qx[0], qy[0] > 0 ? qy[0] - 1 : 0, qbest[0], cx0, cy0, cx1, cy1) || ray_can_hit(qx[1], qy[1] > 0 ? qy[1] - 1 : 0, qbest[1], cx0, cy0, cx1, cy1)))
           keep |= 1ull << c;
       }
       return keep;
@@ -1944,8 +1943,10 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
       if (lvl > 1) {
-        const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane];
-        const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane];
+        uint32_t lane_here = (uint32_t) lane;  // (see the leaf branch)
+        asm volatile("" : "+v"(lane_here));
+        const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane_here];
+        const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane_here];
         uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
         if (sp + __popcll(m) > stack_cap) { ovf = true; break; }  // (the group leaves the walk: see kWalkStack)
         if ((m >> lane) & 1)
@@ -1955,8 +1956,12 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         wave_lds_fence();
       } else {
         const uint32_t slot0 = idx * 64;
-        const QBox bb = T.box0[(uint64_t) slot0 + lane];  // one base segment per lane, sorted by x0
-        const uint2 tab = T.xtab[(uint64_t) slot0 + lane];
+        // (the lane offset passes through an empty asm: left alone the compiler keeps base + 16 lane and base + 8 lane of
+        //  the two arrays in four VGPRs through the whole traversal, and the kernel needs its 56)
+        uint32_t lane_here = (uint32_t) lane;
+        asm volatile("" : "+v"(lane_here));
+        const QBox bb = T.box0[(uint64_t) slot0 + lane_here];  // one base segment per lane, sorted by x0
+        const uint2 tab = T.xtab[(uint64_t) slot0 + lane_here];
         const uint32_t sx0s = __builtin_amdgcn_readfirstlane((uint32_t) ex0);
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
         bool changed = false;
@@ -1982,7 +1987,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
             const int ja = j << 2;
             const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, bb.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, bb.x1);
             const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, bb.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, bb.y1);
-            if ((sx0 <= qx[p]) & (qx[p] <= sx1) & (sy1 >= qym1[p]) & (qbest[p] >= sy0) & (j >= jlo)) {
+            if ((sx0 <= qx[p]) & (qx[p] <= sx1) & (sy1 >= qy[p] - 1) & (qbest[p] >= sy0) & (j >= jlo)) {
               const bool certain = sx0 < qx[p] && qx[p] < sx1 && sy0 > qy[p];
               const bool replace = certain && sy1 < sure_y0[p];
               const bool first = cand_at[p] == cand_base[p];
@@ -2029,12 +2034,15 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
+      // (the point's index is read again rather than held in a register through the traversal: the kernel keeps to 56
+      //  VGPRs, six of its blocks fit beside two of k_lsi2)
+      const uint32_t ip = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
       const bool done = valid[p] && !ovf && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
       if (done) {
         const bool hit = cand_at[p] != cand_base[p];
         const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
-        __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip[p]);
-        if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip[p]);
+        __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip);
+        if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip);
       }
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
       const bool listed = valid[p] && !done && !ovf && fill <= (uint32_t) kWalkList;
@@ -2052,7 +2060,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(A.rest_count, (unsigned long long) __popcll(rm));
         base = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) base);
-        if (rest) A.rest[base + rank_below(rm)] = ip[p];
+        if (rest) A.rest[base + rank_below(rm)] = ip;
       }
     }
     wave_lds_fence();  // (the lists are reused by the next group)
@@ -2448,9 +2456,16 @@ int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu) {
   const size_t left = (size_t) 160 * 1024 > (size_t) lsi_blocks_per_cu * 17920 ? (size_t) 160 * 1024 - (size_t) lsi_blocks_per_cu * 17920 : 0;
   int n = (int) (left / block);
   if (n > 8 - lsi_blocks_per_cu) n = 8 - lsi_blocks_per_cu;
-  // ... and 80 of a SIMD's 512 VGPRs per wave of k_lsi2, 64 per wave of the walk: 5 beside 2.  (Tried: k_lsi2 held to
-  // 64 VGPRs so that 6 fit -- 14 spilled registers make it 48 % slower, and the walk gains nothing from the sixth block.)
-  const int by_vgpr = (512 - lsi_blocks_per_cu * 80) / 64;
+  // ... and of a SIMD's 512 VGPRs 80 per wave of k_lsi2 and 56 per wave of the walk (it is kept to that: the point
+  // indices are read again at the end, base + lane addresses are not held): 6 beside 2.  (At 64 it was 5 beside 2.
+  // Tried: k_lsi2 held to 64 VGPRs instead -- 14 spilled registers make it 48 % slower.)
+  static int walk_regs = 0, lsi_regs = 0;
+  if (!walk_regs) {
+    hipFuncAttributes fa;
+    walk_regs = hipFuncGetAttributes(&fa, (const void*) k_pip_walk2) == hipSuccess && fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 64;
+    lsi_regs = hipFuncGetAttributes(&fa, (const void*) k_lsi2) == hipSuccess && fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 80;
+  }
+  const int by_vgpr = (512 - lsi_blocks_per_cu * lsi_regs) / walk_regs;
   if (n > by_vgpr) n = by_vgpr;
   if (n > pip_walk2_blocks_per_cu(top)) n = pip_walk2_blocks_per_cu(top);
   return n < 1 ? 1 : n;
