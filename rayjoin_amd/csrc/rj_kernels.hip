@@ -1842,7 +1842,8 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 __host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256 * 2; }
 
 // (96 SGPRs: above that the hardware admits one block per CU fewer than the occupancy query reports, and the shared
-//  schedule's 5 walk + 2 k_lsi2 blocks per CU no longer fit -- the skyline pointer took it to 100: 0.785 -> 0.852 ms)
+//  schedule's walk + k_lsi2 blocks per CU no longer fit -- the skyline pointer took it to 100: 0.785 -> 0.852 ms.
+//  256 threads x 9 blocks: the compiler then aims below 57 VGPRs -- at 56, six blocks fit beside two of k_lsi2's 80)
 __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk2(PipArgs A) {
   extern __shared__ uint4 walk_smem[];
   const int lane = lane_id();
