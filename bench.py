@@ -181,12 +181,27 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
 
     phases = []  # debug (RJ_BENCH_STEP_TIMES): host clock at the end of enqueueing / main stream done / all done / timers read
 
-    def step(record, with_gather=True):
+    def read_sample():
+        """the stage timers of the last sampled step (its events stay as they are while the following steps record none)"""
+        if not state.get("sample_pending"):
+            return
+        state["sample_pending"] = False
+        lsi_ms.append(h.last_ms(_capi.RJ_T_LSI_KERNEL))
+        pip_ms.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
+        pts_ms.append(h.last_ms(_capi.RJ_T_LSI_POINTS))
+        if state["two_pass"]:
+            walk_ms.append(h.last_ms(_capi.RJ_T_PIP_WALK))
+
+    def step(record, with_gather=True, sample=False):
         t_begin = time.perf_counter()
         closest = closest2[state["k"] % len(closest2)]
         state["k"] += 1
-        # the stage timers (HIP events around every stage) are recorded on the steps whose timers are read: every fourth
-        sample = bool(record) and (state["k"] % 4 == 0 or not lsi_ms)
+        # the stage timers (HIP events around every stage) are recorded on the sampled steps only -- every fourth timed step,
+        # counted back from the last -- and READ later: before the next sampled step overwrites them, or behind the barrier
+        # that closes the timed steps (reading them is ~60 us of host time that used to sit inside the sampled step)
+        sample = bool(record) and sample
+        if sample:
+            read_sample()
         if sample != state.get("timers_on", True):
             h.set_option("timers", 1 if sample else 0)
             state["timers_on"] = sample
@@ -213,14 +228,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         t_main = time.perf_counter()
         h.sync()  # joins the PIP kernels, which run on the handle's second stream beside the LSI kernel
         t_all = time.perf_counter()
-        if sample:  # (one call for all stages, every fourth step: it sits between two steps)
-            ms = h.last_ms_all()
-
-            lsi_ms.append(ms[_capi.RJ_T_LSI_KERNEL])
-            pip_ms.append(ms[_capi.RJ_T_PIP_KERNEL])
-            pts_ms.append(ms[_capi.RJ_T_LSI_POINTS])
-            if state["two_pass"]:
-                walk_ms.append(ms[_capi.RJ_T_PIP_WALK])
+        if sample:
+            state["sample_pending"] = True
         if DEBUG_PHASES and record and world == 1:
             phases.append((t_begin, t_enq, t_main, t_all, time.perf_counter()))
         if pg is not None and with_gather:  # all-gather of this step's PIP result queue, behind the next step's kernels
@@ -310,11 +319,12 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         barrier()
         t0 = time.perf_counter()
         marks = []
-        for _ in range(k):
-            step(True, with_gather)
+        for i in range(k):
+            step(True, with_gather, sample=(k - 1 - i) % 4 == 0)
             marks.append(time.perf_counter())
         barrier()
         el = time.perf_counter() - t0
+        read_sample()
         state["step_ms"] = [(b - a) * 1e3 for a, b in zip([t0] + marks, marks)]  # (this rank's host clock per step)
         if DEBUG_PHASES and rank == 0 and phases:
             ph = np.array(phases[-k:]) * 1e3
@@ -339,6 +349,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     h.lsi_query(0, 1, e0, e1, cap, pairs)
     h.pip_query(0, 1, None, p0, p1 - p0, closest2[0], faces)
     gc.collect()  # (before the warm-up steps, not between them and the timed ones: the GPU's clocks drop while the host collects)
+    torch.cuda.synchronize()  # (torch's device context comes up at its first call: not inside the barrier that opens the timed steps)
     for _ in range(warmup):
         step(False)
     # the kernel schedule must be settled before anything is timed: four measured pairs do it, i.e. the fifth
