@@ -12,6 +12,15 @@ pytestmark = pytest.mark.gpu
 
 
 def _maps(rng):
+    """a generator's output that is a planar graph the loader accepts (chains of >= 2 points: planar_graph.h:71)"""
+    while True:
+        g = _draw(rng)
+        probe = maps.Context([g]).load().maps[0]
+        if probe.n_edges > 0 and np.all(np.diff(probe.row_index) >= 2) and np.all(np.isfinite(probe.pts.astype(np.float64))):
+            return g
+
+
+def _draw(rng):
     kind = rng.integers(0, 5)
     seed = int(rng.integers(1, 1 << 30))
     if kind == 0:
