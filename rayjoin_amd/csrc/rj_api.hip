@@ -1601,9 +1601,11 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     // Two points per lane (k_pip_walk2: one traversal per 128 positions) where the query set is large enough for full
     // 64-position groups and nobody is counting visits: headline step -5.5 %, Zipcode -6 %, nested -5 %.  (The walk's
     // stack is cut at kWalkStack entries whatever the tree's height, so eight blocks per CU fit on every tree.)
+    // From four 128-position groups per resident wave on: below that -- a 1/8 shard of the headline's query map -- the
+    // one-point kernel's smaller groups fill the waves better (1/8 shard, pipelined step: 0.203 -> 0.190 ms).
     const bool two = h->walk_points == 2 && !h->stats_on && w.group_lanes == 64 && !h->chunk_groups &&
                      pip_walk2_blocks_per_cu(w.bvh.top) >= 6 &&
-                     n >= (uint64_t) 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top);  // (two 128-position groups per resident wave)
+                     n >= (uint64_t) 2 * 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top);  // (four 128-position groups per resident wave)
     tic(h, RJ_T_PIP_WALK, st);
     // a base map with a column index (isolated rings): the first pass reads the point's strip instead of walking the tree
     const bool columns = w.bvh.strips.ytab != nullptr && !h->stats_on;

@@ -190,16 +190,16 @@ def test_uscounty_zipcode_overlay_stages_full_size():
 
 def test_walk_two_points_per_lane_equals_one_and_the_single_kernel():
     """k_pip_walk2 (128 positions per wave, "pip_walk_points" 2, the default where it applies) against k_pip_walk and
-    against k_pip alone on a nested pair large enough for full 64-position groups (2.6 M query vertices, a quarter of
-    them on base vertices): closest eids and face ids of every vertex, bit for bit; and it is what ran."""
-    ctx = maps.Context([synth.standin("USCounty", 0.3), synth.standin("NestedBlockGroup", 0.3)]).load()
+    against k_pip alone on a nested pair large enough for four 128-position groups per resident wave (4.6 M query
+    vertices, a quarter of them on base vertices): closest eids and face ids of every vertex, bit for bit; and it is what ran."""
+    ctx = maps.Context([synth.standin("USCounty", 0.4), synth.standin("NestedBlockGroup", 0.4)]).load()
     base, query = ctx.maps
     h = _capi.Handle(0)
     h.upload_map(0, base.pts, base.row_index, base.left, base.right)
     h.upload_map(1, query.pts, query.row_index, query.left, query.right)
     h.build_lbvh(0)
     n = query.n_points
-    assert n > 1 << 21
+    assert n > 1 << 22
     out = {}
     for name, walk, pts in (("two", 2, 2), ("one", 2, 1), ("single", 0, 1)):
         h.set_option("pip_walk", walk)

@@ -134,7 +134,7 @@ def test_groups_that_outgrow_the_walks_stack_leave_the_walk(oracle, walk_points)
     out: closest edges and face ids (pip_lbvh.h:25-142 semantics) must not change, with one and with two points per
     lane, synchronous and asynchronous."""
     oracle.lib().rjo_set_num_threads(16)
-    scale = 0.12 if walk_points == 1 else 0.3  # (two points per lane: from two 128-position groups per resident wave on)
+    scale = 0.12 if walk_points == 1 else 0.4  # (two points per lane: from four 128-position groups per resident wave on)
     ctx = maps.Context([synth.standin("USCounty", scale), synth.standin("BlockGroup", scale)]).load()
     b, q = ctx.maps
     m0 = oracle.Map(b.pts, b.row_index, b.left, b.right)
