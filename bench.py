@@ -598,6 +598,11 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         if ms_synced is not None:
             out["ms_per_step_synced"] = round(ms_synced, 4)        # every step ending in the host's read of the gathered heads
         out["pipelined"] = ms_synced is not None
+        # the ranks that ran: the launcher's count, and -- on the native transport -- what RCCL counts in the handle's communicator
+        out["ranks"] = {"world_size": world, "rccl_comm_ranks": h.get_option("comm_ranks") or None,
+                        "transport": ("gloo (one-GPU rehearsal: every rank on cuda:0)" if args.rehearse_one_gpu else "rccl") if world > 1 else None}
+        if world > 1 and not args.rehearse_one_gpu and out["ranks"]["rccl_comm_ranks"] != world:
+            raise SystemExit("bench.py: RCCL counts %s ranks in the communicator, the launcher %d" % (out["ranks"]["rccl_comm_ranks"], world))
         if world > 1:
             out["multi_gpu_note"] = ("no hardware curve exists for N > 1 in this repository's records: this line is whatever node ran it; "
                                      "single-GPU emulations of a shard (--emulate-shard) are diagnostics, not scaling results")
@@ -614,8 +619,34 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves -- torch.distributed.run as
+    a CHILD process, before this process has imported torch or touched the GPU (no exec from a process that holds a GPU
+    context) -- relay its output (rank 0 prints the one JSON line) and leave with its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL across processes needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        # a line that says n_gpus = WORLD_SIZE under a command that says --gpus N would be a lie either way: refuse
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; start it as `python bench.py --gpus N` "
+                 "(it launches its own ranks) or with a matching --nproc-per-node" % (args.gpus, os.environ["WORLD_SIZE"]))
     import torch
     import torch.distributed as dist
 

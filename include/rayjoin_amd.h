@@ -345,7 +345,8 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  *   "pip_schedule" (0 turns, 1 shared, 2 full grids, -1 still trying), "pip_schedule_trials", "pip_schedule_us0/1/2",
  *   "lsi_share_blocks", "pip_share_blocks"                      what "pip_concurrent" 2 measured and settled on
  *   "lsi_last_segments", "pip_last_walk_points", "pip_last_passes", "lsi_points_last_split", "lsi_points_gcd_pairs",
- *   "pip_rest", "pip_rest_aux", "query_last_ordered", "pip_last_columns"            what the last query ran */
+ *   "pip_rest", "pip_rest_aux", "query_last_ordered", "pip_last_columns"            what the last query ran
+ *   "comm_ranks"                                                the ranks RCCL counts in the handle's communicator (0: none) */
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 int rj_get_option(rj_handle h, const char* name, int64_t* value);
 /* Experiment knobs for tools/ and the fault-path tests -- grids, chunk sizes, run lengths ("chunk_groups",

@@ -607,6 +607,11 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "closed_chains0") || !strcmp(name, "closed_chains1")) *value = (int64_t) h->map[name[13] - '0'].closed_chains;
   else if (!strcmp(name, "pip_rest")) *value = (int64_t) h->h_rest[0];  // points the last finished two-pass query on the main stream left to k_pip (-1: none yet)
   else if (!strcmp(name, "pip_rest_aux")) *value = (int64_t) h->h_rest[1];
+  else if (!strcmp(name, "comm_ranks")) {  // the ranks RCCL itself counts in the handle's communicator (0: rj_comm_init was not called)
+    int c = 0;
+    if (h->comm && ncclCommCount(h->comm, &c) != ncclSuccess) return fail(h, RJ_E_HIP, "ncclCommCount failed");
+    *value = c;
+  }
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
   else if (!strcmp(name, "pip_share_blocks")) *value = h->last_pip_share ? h->last_pip_share : h->pip_share_blocks();
   else return fail(h, RJ_E_INVALID, "unknown option '%s'", name);

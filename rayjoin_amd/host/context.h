@@ -60,6 +60,7 @@ inline void rj_check(rj_handle h, int rc, const char* what) {
 
 // host-side image of one scaled map (what rj_upload_map takes)
 struct HostMap {
+  struct point_t { int64_t x, y; };  // a scaled point as the device holds it (Map::point_t, src/map/map.h:53: cuda_vec<int64_t>::type_2d)
   std::vector<int64_t> xy;          // 2*np
   std::vector<uint32_t> row_index;  // nc+1
   std::vector<int64_t> left, right; // nc
@@ -101,6 +102,7 @@ class Stream {
     rj_check(h_, own_ ? rj_set_option(h_, "own_stream", 1) : rj_set_stream(h_, native_), "rj_set_stream");
   }
   void* native() const { return native_; }
+  void* cuda_stream() const { return native_; }  // (the reference's accessor, src/util/stream.h:55: nullptr = the handle's own stream)
 
  private:
   rj_handle h_;
@@ -110,6 +112,11 @@ class Stream {
 
 class Context {
  public:
+  // the type names the reference's operators take from their CONTEXT_T (src/context.h:19-24)
+  using coord_t = double;
+  using internal_coord_t = int64_t;
+  using coefficient_t = __int128;
+  using map_t = HostMap;
   explicit Context(const std::array<std::shared_ptr<PlanarGraph>, 2>& pgs, int device = 0, bool fused_scaling = false) : pgraphs_(pgs) {
     for (auto& g : pgs)
       if (g) {

@@ -5,6 +5,7 @@
 //   -mode=rt   : rejected -- gfx950 has no ray-tracing units (the reference's OptiX path)
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <fstream>
 #include <iostream>
@@ -13,6 +14,7 @@
 #include "context.h"
 #include "flags.h"
 #include "lsi_pip.h"
+#include "lsi_amd.h"
 #include "timer.h"
 
 using namespace rayjoin;
@@ -128,9 +130,9 @@ bool CheckPIPResult(Context& ctx, const Flags& f, const int64_t* d_pts, size_t n
   rj_handle h = ctx.handle();
   std::cerr << "Checking point in polygon" << std::endl;
   rj_check(h, rj_build_grid(h, 0, f.grid_size), "rj_build_grid");
-  PIPGrid pip_grid(ctx);
+  PIPGrid<Context> pip_grid(ctx);
   pip_grid.Init(n_points);
-  pip_grid.Query(ctx.get_stream(), 1, d_pts, n_points);
+  pip_grid.Query(ctx.get_stream(), 1, ArrayView<HostMap::point_t>((HostMap::point_t*) d_pts, n_points));
   std::vector<uint32_t> ans;
   pip_grid.get_closest_eids(ans);
   auto base = ctx.get_map(0);
@@ -165,7 +167,8 @@ bool CheckPIPResult(Context& ctx, const Flags& f, const int64_t* d_pts, size_t n
 }
 
 void CheckMode(const Flags& f) {
-  if (f.mode == "lbvh" || f.mode == "grid") return;
+  // "amd": the same LBVH path through the adapter classes a RayJoin maintainer would add (host/lsi_amd.h)
+  if (f.mode == "lbvh" || f.mode == "grid" || f.mode == "amd") return;
   if (f.mode == "rt") throw std::runtime_error("-mode=rt needs RT cores/OptiX; MI355X (gfx950) has none: use -mode=lbvh");
   throw std::runtime_error("Invalid index type: " + f.mode);
 }
@@ -191,8 +194,15 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
   tm.next("Create App");
   const bool grid = f.mode == "grid";
   if (grid && f.nranks > 1) throw std::invalid_argument("-mode=grid joins the two whole maps: no -nranks");
-  std::unique_ptr<LSI> lsi_p(grid ? (LSI*) new LSIGrid(*ctx) : (LSI*) new LSILBVH(*ctx));
-  LSI& lsi = *lsi_p;
+  const bool amd = f.mode == "amd";
+  if (amd && f.nranks > 1) throw std::invalid_argument("-mode=amd is the single-GPU adapter: use -mode=lbvh with -nranks");
+  LSIAMD<Context>* lsi_amd = amd ? new LSIAMD<Context>(*ctx, ctx->handle()) : nullptr;
+  std::unique_ptr<LSI<Context>> lsi_p(amd ? (LSI<Context>*) lsi_amd : grid ? (LSI<Context>*) new LSIGrid<Context>(*ctx) : (LSI<Context>*) new LSILBVH<Context>(*ctx));
+  LSI<Context>& lsi = *lsi_p;
+  // (get_xsects / size are not virtual in the reference's LSI either: the adapter's results are read through its own type)
+  auto n_found = [&]() { return lsi_amd ? lsi_amd->size() : lsi.size(); };
+  auto d_pairs = [&]() { return lsi_amd ? lsi_amd->get_pairs() : lsi.get_pairs(); };
+  auto d_xsects = [&]() { return lsi_amd ? lsi_amd->get_xsects() : lsi.get_xsects(); };
   tm.next("Load Data");
   ctx->LoadToDevice();
   if (gen_queries) ctx->set_map(1, gen_queries);
@@ -206,7 +216,7 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
     ctx->get_map(1)->shard(f.nranks, f.rank, &e0, &e1, &p0, &p1);
     std::cerr << "Rank " << f.rank << "/" << f.nranks << ": query eids [" << e0 << ", " << e1 << ")" << std::endl;
   }
-  lsi.set_query_range(e0, e1);
+  if (!amd) lsi.set_query_range(e0, e1);
   tm.next("Build Index");
   if (grid) {  // run_query.cu:247-249: AddMapsToGrid
     rj_check(ctx->handle(), rj_build_grid(ctx->handle(), 0, f.grid_size), "rj_build_grid");
@@ -232,12 +242,16 @@ void RunLSIQuery(const Flags& f) {  // run_query.cu:169-314
     uint64_t total = lsi.AllGather(queue_cap);
     std::cerr << "Rank " << f.rank << ": local intersections " << lsi.local_size() << ", all ranks " << total << std::endl;
   }
-  std::cerr << "Intersections: " << lsi.size() << " Queue Load Factor: " << (double) lsi.size() / (queue_cap ? queue_cap : 1)
+  std::cerr << "Intersections: " << n_found() << " Queue Load Factor: " << (double) n_found() / (queue_cap ? queue_cap : 1)
             << std::endl;
   if (f.repeat > 0) std::cerr << "LSI kernel (HIP events): " << kernel_ms / f.repeat << " ms" << std::endl;
   if (!f.output.empty()) {
-    std::vector<rj_xsect> xs;
-    lsi.CopyTo(xs);
+    // d_xsects = lsi->get_xsects() (run_query.cu:304): the records Query left on the device, in queue order; the file
+    // lists them by (eid[0], eid[1]) -- sorted on the host, where the reference's checker sorts (run_overlay.cu:38-52)
+    std::vector<rj_xsect> xs(d_xsects().size());
+    rj_check(ctx->handle(), rj_memcpy_d2h(ctx->handle(), xs.data(), d_xsects().data(), sizeof(rj_xsect) * xs.size()), "rj_memcpy_d2h");
+    std::sort(xs.begin(), xs.end(), [](const rj_xsect& a, const rj_xsect& b) { return a.eid[0] != b.eid[0] ? a.eid[0] < b.eid[0] : a.eid[1] < b.eid[1]; });
+    (void) d_pairs;
     FILE* fp = fopen(f.output.c_str(), "w");
     if (!fp) throw std::runtime_error("Cannot write " + f.output);
     for (auto& x : xs) fprintf(fp, "%u %u %ld %ld\n", x.eid[0], x.eid[1], (long) x.x_num, (long) x.y_num);
@@ -276,8 +290,11 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   }
   tm.next("Create App");
   const bool grid = f.mode == "grid";
-  std::unique_ptr<PIP> pip_p(grid ? (PIP*) new PIPGrid(*ctx) : (PIP*) new PIPLBVH(*ctx));
-  PIP& pip = *pip_p;
+  const bool amd = f.mode == "amd";
+  PIPAMD<Context>* pip_amd = amd ? new PIPAMD<Context>(*ctx, ctx->handle()) : nullptr;
+  std::unique_ptr<PIP<Context>> pip_p(amd ? (PIP<Context>*) pip_amd : grid ? (PIP<Context>*) new PIPGrid<Context>(*ctx) : (PIP<Context>*) new PIPLBVH<Context>(*ctx));
+  PIP<Context>& pip = *pip_p;
+  const ArrayView<HostMap::point_t> query_points((HostMap::point_t*) d_pts, n_points);  // (no array: every vertex of the query map)
   tm.next("Init");
   pip.Init(n_points);
   tm.next("Build Index");
@@ -288,17 +305,22 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   if (f.profile) PrintBuildProfile(*ctx, grid);
   tm.next("Warmup");
   Stream& stream = ctx->get_stream();
-  for (int i = 0; i < f.warmup; i++) pip.Query(stream, 1, d_pts, n_points);
+  for (int i = 0; i < f.warmup; i++) pip.Query(stream, 1, query_points);
   tm.next("Query", f.repeat);
   float kernel_ms = 0;
   for (int i = 0; i < f.repeat; i++) {
-    pip.Query(stream, 1, d_pts, n_points);
+    pip.Query(stream, 1, query_points);
     float ms = 0;
     rj_last_ms(ctx->handle(), RJ_T_PIP_KERNEL, &ms);
     kernel_ms += ms;
   }
   std::vector<uint32_t> eids;
-  pip.get_closest_eids(eids);
+  if (pip_amd) {
+    eids.resize(pip_amd->get_closest_eids().size());
+    rj_check(ctx->handle(), rj_memcpy_d2h(ctx->handle(), eids.data(), pip_amd->get_closest_eids().data(), 4 * eids.size()), "rj_memcpy_d2h");
+  } else {
+    pip.get_closest_eids(eids);
+  }
   bool check_ok = true;
   if (f.check && !grid) {  // run_query.cu:449-455
     tm.next("Check");
@@ -311,7 +333,14 @@ void RunPIPQuery(const Flags& f) {  // run_query.cu:316-462
   if (f.repeat > 0) std::cerr << "PIP kernel (HIP events): " << kernel_ms / f.repeat << " ms" << std::endl;
   if (!f.output.empty()) {
     std::vector<int32_t> faces;
-    pip.get_face_ids(faces);
+    if (pip_amd) {  // (the adapter mirrors the reference's PIP, which has no face ids: a second query through the operator that has)
+      PIPLBVH<Context> with_faces(*ctx);
+      with_faces.Init(n_points);
+      with_faces.Query(stream, 1, query_points);
+      with_faces.get_face_ids(faces);
+    } else {
+      pip.get_face_ids(faces);
+    }
     FILE* fp = fopen(f.output.c_str(), "w");
     if (!fp) throw std::runtime_error("Cannot write " + f.output);
     for (size_t i = 0; i < eids.size(); i++) fprintf(fp, "%u %d\n", eids[i], faces[i]);

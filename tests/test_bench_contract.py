@@ -63,3 +63,16 @@ def test_traffic_file_matches_the_kernels_bench_reports():
         assert t["sq"][k]["SQ_ACTIVE_INST_VALU"] > 0 and t["sq"][k]["GRBM_GUI_ACTIVE"] > 0
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "kernel_source_hash" in src and "stale" in src
+
+
+def test_gpus_flag_and_world_size_must_agree():
+    """A launcher that started WORLD_SIZE ranks under a command line that says --gpus N is refused before anything
+    touches the GPU (runs here, without one): the line's n_gpus can only be what both say."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr and not r.stdout.strip()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    # N > 1 without a launcher: the ranks are a CHILD process started before torch is imported (no exec from a GPU process)
+    assert src.index("sys.exit(launch_ranks(args))") < src.index("import torch\n    import torch.distributed as dist")

@@ -53,6 +53,22 @@ def test_query_exec_lsi_and_pip(oracle, tmp_path):
                         "-warmup", "0", "-repeat", "1", "-output", outpg], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(outpg).read() == open(outp).read()
+    # -mode=amd: the adapter classes of INTEGRATION.md section 2 (host/lsi_amd.h: LSIAMD / PIPAMD, subclasses of the operator
+    # interfaces written against the C ABI alone), compiled into the binary -- same files as -mode=lbvh, byte for byte
+    outa = str(tmp_path / "pairs_amd.txt")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "amd", "-xsect_factor", "0.5",
+                        "-warmup", "1", "-repeat", "2", "-output", outa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert int(re.search(r"Intersections: (\d+)", r.stderr).group(1)) == len(want)
+    assert open(outa).read() == open(out).read()
+    outpa = str(tmp_path / "pip_amd.txt")
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "pip", "-mode", "amd", "-warmup", "1",
+                        "-repeat", "1", "-output", outpa], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(outpa).read() == open(outp).read()
+    r = subprocess.run([EXE, "-poly1", p0, "-poly2", p1, "-query", "lsi", "-mode", "amd", "-xsect_factor", "0.000001",
+                        "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "overflow" in r.stderr
     # generated workloads (no -poly2) run and overflow is a reported error, not UB
     r = subprocess.run([EXE, "-poly1", p0, "-query", "lsi", "-mode", "lbvh", "-gen_n", "2000", "-gen_t", "5",
                         "-seed", "3", "-warmup", "0", "-repeat", "1"], capture_output=True, text=True)

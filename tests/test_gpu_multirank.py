@@ -23,9 +23,11 @@ def _free_port():
     return p
 
 
-def _bench(nproc, extra=()):
+def _bench(nproc, extra=(), plain=False):
     common = ["bench.py", "--gpus", str(nproc), "--steps", "2", "--warmup", "1", "--scale", "0.12", "--no-cpu-baseline"]
-    if nproc > 1:
+    if plain:  # the driver's single-GPU form with N > 1: bench.py starts its own ranks (a child torch.distributed.run)
+        cmd = [sys.executable] + common + ["--rehearse-one-gpu"]
+    elif nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + common + ["--rehearse-one-gpu"]
     else:
@@ -47,3 +49,12 @@ def test_two_and_three_ranks_reproduce_the_single_gpu_results():
         assert many["intersections"] == one["intersections"]
         assert many["result_digest"] == one["result_digest"], (nproc, many["result_digest"], one["result_digest"])
         assert "chain range x%d" % nproc in many["config"]["sharding"]
+
+
+def test_plain_command_with_gpus_2_starts_two_ranks():
+    """`python bench.py --gpus 2` without a launcher around it must not print a one-rank line that says two."""
+    one = _bench(1)
+    two = _bench(2, plain=True)
+    assert two["n_gpus"] == 2 and two["ranks"]["world_size"] == 2
+    assert "chain range x2" in two["config"]["sharding"]
+    assert two["intersections"] == one["intersections"] and two["result_digest"] == one["result_digest"]

@@ -35,6 +35,51 @@ def test_oracle_pipeline_reproduces_overlay_answer(oracle, tmp_path):
         assert (xs[im]["mid_point_polygon_id"][~last] >= 0).all()
 
 
+def _writer_twin():
+    """tests/hosttwin/output_chain_twin.cc: the product's output-map writer (host/output_chain.h) driven without a GPU"""
+    src = os.path.join(ROOT, "tests", "hosttwin", "output_chain_twin.cc")
+    hdr = os.path.join(ROOT, "rayjoin_amd", "host")
+    out = os.path.join(ROOT, "tests", "hosttwin", "_build", "output_chain_twin")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(hdr, "output_chain.h")), os.path.getmtime(os.path.join(hdr, "planar_graph.h")))
+    if not os.path.exists(out) or os.path.getmtime(out) < newest:
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-pthread", "-I", hdr, "-o", out, src,
+                               "-L", os.path.join(ROOT, "rayjoin_amd"), "-lrayjoin_amd", "-Wl,-rpath," + os.path.join(ROOT, "rayjoin_amd"),
+                               "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+@pytest.mark.parametrize("pair", ["sample", "lattice", "rings"])
+def test_product_writer_reproduces_the_oracle_pipelines_file(oracle, tmp_path, pair):
+    """The C++ writer that polyover_exec uses -- chains cut into pieces, pieces labelled, faces and points numbered --
+    fed the oracle pipeline's records and vertex faces must write the oracle pipeline's file byte for byte (on the sample
+    pair that is the committed overlay answer).  No GPU: this is the host pass alone."""
+    if pair == "sample":
+        p0, p1 = os.path.join(D, "map0.cdb"), os.path.join(D, "map1.cdb")
+    else:
+        g0, g1 = ((synth.lattice_map(5, 40, 61), synth.lattice_map(9, 22, 62)) if pair == "lattice"
+                  else (synth.ring_map(60, 900, seed=63), synth.lattice_map(6, 30, 64)))
+        p0, p1 = str(tmp_path / "a.cdb"), str(tmp_path / "b.cdb")
+        maps.write_cdb(p0, g0, "%.9f")
+        maps.write_cdb(p1, g1, "%.9f")
+    ctx = maps.Context([maps.read_cdb(p0), maps.read_cdb(p1)]).load()
+    want = str(tmp_path / "want.txt")
+    (nch, nfc), xs, pip = overlay_ref.oracle_overlay(oracle, ctx, want, 256)
+    files = []
+    for im in range(2):
+        fx, fp = str(tmp_path / ("xs%d.bin" % im)), str(tmp_path / ("pip%d.bin" % im))
+        np.ascontiguousarray(xs[im]).tofile(fx)
+        np.ascontiguousarray(pip[im], dtype=np.int32).tofile(fp)
+        files += [fx, fp]
+    got = str(tmp_path / "got.txt")
+    r = subprocess.run([_writer_twin(), p0, p1, files[0], files[2], files[1], files[3], got], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == [str(nch), str(nfc)]
+    assert open(got).read() == open(want).read()
+    if pair == "sample":
+        assert open(got).read() == open(os.path.join(D, "overlay_answer.txt")).read()
+
+
 def test_polyover_cli_errors():
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 1 and "Usage" in r.stderr
