@@ -428,6 +428,12 @@ class Handle:
         self._check(self.L.rj_last_ms_all(self.h, buf, 12))
         return list(buf)
 
+    def last_stats_raw(self):
+        """the 16 counters as a list (what each slot means depends on the instrumented kernel that ran: rj_kernels.hip)"""
+        s = (_u64 * 16)()
+        self._check(self.L.rj_last_stats(self.h, s))
+        return list(s)
+
     def last_stats(self):
         s = (_u64 * 16)()
         self._check(self.L.rj_last_stats(self.h, s))

@@ -453,7 +453,7 @@ int rj_create(int device_id, rj_handle* out) {
   h->device = device_id;
   if (const char* e = getenv("RJ_LEAF_ORDER")) h->leaf_order = atoi(e) == 0 ? 0 : 1;
   if (const char* e = getenv("RJ_LSI_SEGMENTS")) h->lsi_segments = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
-  if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
+  if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : (atoi(e) == 4 ? 4 : 2);  // (A/B runs)
   if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
   {
     hipDeviceProp_t prop;
@@ -651,7 +651,7 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     return RJ_OK;
   }
   if (!strcmp(name, "pip_walk_points")) {
-    if (value != 1 && value != 2) return fail(h, RJ_E_INVALID, "pip_walk_points: 1 or 2");
+    if (value != 1 && value != 2 && value != 4) return fail(h, RJ_E_INVALID, "pip_walk_points: 1, 2 or 4");
     h->walk_points = (int) value;
     return RJ_OK;
   }
@@ -1608,9 +1608,10 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     // stack is cut at kWalkStack entries whatever the tree's height, so eight blocks per CU fit on every tree.)
     // From four 128-position groups per resident wave on: below that -- a 1/8 shard of the headline's query map -- the
     // one-point kernel's smaller groups fill the waves better (1/8 shard, pipelined step: 0.203 -> 0.190 ms).
-    const bool two = h->walk_points == 2 && !h->stats_on && w.group_lanes == 64 && !h->chunk_groups &&
-                     pip_walk2_blocks_per_cu(w.bvh.top) >= 6 &&
-                     n >= (uint64_t) 2 * 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top);  // (four 128-position groups per resident wave)
+    const int wp = h->walk_points == 4 ? 4 : 2;  // (four per lane: 256 positions per wave, half the blocks per CU)
+    const bool two = h->walk_points >= 2 && w.group_lanes == 64 && !h->chunk_groups &&
+                     pip_walk2_blocks_per_cu(w.bvh.top, wp) >= (wp == 4 ? 3 : 6) &&
+                     n >= (uint64_t) wp * 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top, wp);  // (four groups per resident wave)
     tic(h, RJ_T_PIP_WALK, st);
     // a base map with a column index (isolated rings): the first pass reads the point's strip instead of walking the tree
     const bool columns = w.bvh.strips.ytab != nullptr && !h->stats_on;
@@ -1620,9 +1621,9 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
       RJ_HIP(h, launch_pip_strip(st, w, walk_blocks, h->cus));
     } else if (two) {
       if (aux && h->lsi_shared && !h->pip_share_set)
-        walk_blocks = h->cus * pip_walk2_blocks_beside(w.bvh.top, h->lsi_share_blocks() / h->cus < 1 ? 1 : h->lsi_share_blocks() / h->cus);
-      RJ_HIP(h, launch_pip_walk2(st, w, walk_blocks, h->cus));
-      h->last_walk_points = 2;
+        walk_blocks = h->cus * pip_walk2_blocks_beside(w.bvh.top, h->lsi_share_blocks() / h->cus < 1 ? 1 : h->lsi_share_blocks() / h->cus, wp);
+      RJ_HIP(h, launch_pip_walk2(st, w, walk_blocks, h->cus, h->stats_on, wp));
+      h->last_walk_points = wp;
     } else {
       RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
     }

@@ -166,9 +166,9 @@ hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, c
                              unsigned long long* count_hint);
 hipError_t launch_pip(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
 hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a, bool stats, int max_blocks);
-hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a, int max_blocks, int cus);
-int pip_walk2_blocks_per_cu(int top);
-int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu);
+hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a, int max_blocks, int cus, bool stats = false, int points = 2);
+int pip_walk2_blocks_per_cu(int top, int points = 2);
+int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu, int points = 2);
 hipError_t launch_pip_exact(hipStream_t st, const PipArgs& a, int blocks, const PipRestArgs& r);
 int pip_walk_list_slots();  // candidates a todo record holds
 uint32_t pip_walk_group_lanes(uint64_t n, int top, int cus);  // points per wave k_pip_walk uses when the caller leaves it open

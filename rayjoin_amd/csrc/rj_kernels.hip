@@ -297,7 +297,21 @@ __device__ __forceinline__ bool occ_any(const uint32_t* __restrict__ occ, int32_
   return (bits & want) != 0;
 }
 
-// the same test from a segment's 4-byte cell code (cell_code)
+// the same test from a segment's 4-byte cell code (cell_code), in two halves: the bitmap windows are REQUESTED for every
+// lane (no branch around a load, so a kernel can have several sets' windows in flight at once), the verdict comes later
+struct OccWindows { uint64_t a, b; };
+__device__ __forceinline__ OccWindows occ_fetch_code(const uint32_t* __restrict__ occ, uint32_t code) {
+  const int cx0 = code & 0xFFF, cy0 = (code >> 12) & 0xFFF, dy = (code >> 26) & 3;
+  OccWindows w;
+  w.a = *reinterpret_cast<const occ_window_t*>(occ + (size_t) cy0 * kOccRowWords + (cx0 >> 5));
+  w.b = *reinterpret_cast<const occ_window_t*>(occ + (size_t) (cy0 + (dy ? 1 : 0)) * kOccRowWords + (cx0 >> 5));  // (row 4095 + 1: the flag word's row, allocated)
+  return w;
+}
+__device__ __forceinline__ bool occ_verdict_code(const OccWindows& w, uint32_t code) {
+  const int cx0 = code & 0xFFF, dx = (code >> 24) & 3, dy = (code >> 26) & 3;
+  const uint64_t want = (uint64_t) (dx ? 3u : 1u) << (cx0 & 31);
+  return dx > 1 || dy > 1 || ((w.a | w.b) & want) != 0;  // (large box: let the tree decide)
+}
 __device__ __forceinline__ bool occ_any_code(const uint32_t* __restrict__ occ, uint32_t code) {
   const int cx0 = code & 0xFFF, cy0 = (code >> 12) & 0xFFF, dx = (code >> 24) & 3, dy = (code >> 26) & 3;
   if (dx > 1 || dy > 1) return true;  // large box: let the tree decide
@@ -659,7 +673,11 @@ __device__ __forceinline__ bool next_group(unsigned long long* ranges, int wib, 
   }
   // the global queue is dry for good (tried == 8): help a sibling out
   for (int s = 1; s < NWAVES; s++) {
-    const int w = wib + s < NWAVES ? wib + s : wib + s - NWAVES;
+    // (this is the kernel's tail: the siblings' LDS addresses are formed here, when wanted -- left to itself the compiler
+    //  keeps all three in VGPRs through the whole kernel, and k_pip_walk2 has none to spare)
+    int me = wib;
+    asm volatile("" : "+v"(me));
+    const int w = me + s < NWAVES ? me + s : me + s - NWAVES;
     if (take_from(&ranges[w], lane, g)) return true;
   }
   return false;
@@ -777,24 +795,32 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     const long long tkg = STATS ? clock64() : 0;
     const uint64_t qi = g * GL + lane;  // position in the (possibly Morton-sorted) query order
     const bool valid = (uint32_t) lane < GL && qi < nq;
-    const uint64_t q = A.qbeg + (A.order ? (valid ? A.order[qi] : 0) : qi);
+    const uint64_t qc = valid ? qi : nq - 1;  // (an idle lane reads the last query's data: no load stands under a per-lane branch)
+    const uint64_t q = A.qbeg + (A.order ? A.order[qc] : qc);
     int32_t qx0 = kEmptyMin, qy0 = kEmptyMin, qx1 = kEmptyMax, qy1 = kEmptyMax;
     // Pre-filter on the 4-byte cell codes (streamed once): nothing of the base map is near a segment
     // whose cells are clear in the occupancy bitmap.  (Requesting the codes and bitmap windows of
     // four groups together -- two round trips per four groups -- measured +-0: the kernel's time is
     // in the groups that do traverse.)
     bool near = valid;
-    if (valid && occ_usable) near = occ_any_code(T.occ, __builtin_nontemporal_load(A.qcode + q));
+    if (occ_usable) {
+      const uint32_t code = __builtin_nontemporal_load(A.qcode + q);
+      const OccWindows win = occ_fetch_code(T.occ, code);
+      near = valid && occ_verdict_code(win, code);
+    }
     if (!__ballot(near)) {  // the whole group is clear of the base map: its segments are never read
       if (STATS) tk_head += clock64() - tkg;
       continue;
     }
-    if (near) {
+    const QBox root_box = T.lvl[T.top][lane];  // (requested beside the segments: one round trip, not two)
+    {
       const Seg s = A.qseg[q];
-      qx0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
-      qx1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
-      qy0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
-      qy1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+      if (near) {
+        qx0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
+        qx1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
+        qy0 = quant(s.y1 < s.y2 ? s.y1 : s.y2);
+        qy1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+      }
     }
     const int32_t gx0 = wave_min(qx0), gy0 = wave_min(qy0);
     const int32_t gx1 = wave_max(qx1), gy1 = wave_max(qy1);
@@ -815,7 +841,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     };
     int sp = 0;
     {  // top level: <= 64 nodes, one per lane
-      QBox b = T.lvl[T.top][lane];
+      QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
       if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
@@ -946,24 +972,40 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     uint64_t q[2];
     bool near[2];
     int32_t qx0[2], qy0[2], qx1[2], qy1[2];
+    // The loads a group starts with go out in three batches, not seven: both sets' cell codes; both sets' bitmap windows;
+    // then -- only where the pre-filter lets the group through -- both sets' segments beside the root's boxes.  Nothing is
+    // loaded under a per-lane branch (a position past the end reads the last one's): left in `if (valid)` regions every
+    // load was waited for on its own, and this kernel is bound by exactly such chains (SQ_WAIT_ANY 73 % of its wave-cycles).
+    uint32_t code[2];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
       const uint64_t qi = g * 128 + (uint64_t) p * 64 + lane;
-      const bool valid = qi < nq;
-      q[p] = A.qbeg + (A.order ? (valid ? A.order[qi] : 0) : qi);
-      near[p] = valid;
-      if (valid && occ_usable) near[p] = occ_any_code(T.occ, __builtin_nontemporal_load(A.qcode + q[p]));
+      near[p] = qi < nq;
+      const uint64_t qc = near[p] ? qi : nq - 1;
+      q[p] = A.qbeg + (A.order ? A.order[qc] : qc);
+    }
+    if (occ_usable) {
+#pragma unroll
+      for (int p = 0; p < 2; p++) code[p] = __builtin_nontemporal_load(A.qcode + q[p]);
+      OccWindows win[2];
+#pragma unroll
+      for (int p = 0; p < 2; p++) win[p] = occ_fetch_code(T.occ, code[p]);
+#pragma unroll
+      for (int p = 0; p < 2; p++) near[p] = near[p] && occ_verdict_code(win[p], code[p]);
     }
     if (!__ballot(near[0] || near[1])) continue;  // both halves of the group are clear of the base map
+    const QBox root_box = T.lvl[T.top][lane];
+    {
+      Seg sg[2];
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-      qx0[p] = kEmptyMin; qy0[p] = kEmptyMin; qx1[p] = kEmptyMax; qy1[p] = kEmptyMax;
-      if (near[p]) {
-        const Seg s = A.qseg[q[p]];
-        qx0[p] = quant(s.x1 < s.x2 ? s.x1 : s.x2);
-        qx1[p] = quant(s.x1 < s.x2 ? s.x2 : s.x1);
-        qy0[p] = quant(s.y1 < s.y2 ? s.y1 : s.y2);
-        qy1[p] = quant(s.y1 < s.y2 ? s.y2 : s.y1);
+      for (int p = 0; p < 2; p++) sg[p] = A.qseg[q[p]];
+#pragma unroll
+      for (int p = 0; p < 2; p++) {
+        const Seg& s = sg[p];
+        qx0[p] = near[p] ? quant(s.x1 < s.x2 ? s.x1 : s.x2) : kEmptyMin;
+        qx1[p] = near[p] ? quant(s.x1 < s.x2 ? s.x2 : s.x1) : kEmptyMax;
+        qy0[p] = near[p] ? quant(s.y1 < s.y2 ? s.y1 : s.y2) : kEmptyMin;
+        qy1[p] = near[p] ? quant(s.y1 < s.y2 ? s.y2 : s.y1) : kEmptyMax;
       }
     }
     const int32_t gx0 = wave_min(qx0[0] < qx0[1] ? qx0[0] : qx0[1]), gy0 = wave_min(qy0[0] < qy0[1] ? qy0[0] : qy0[1]);
@@ -983,7 +1025,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     };
     int sp = 0;
     {  // top level: <= 64 nodes, one per lane
-      QBox b = T.lvl[T.top][lane];
+      QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
       if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
@@ -1617,14 +1659,15 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     const long long tkg = STATS ? clock64() : 0;
     const uint64_t ipos = (uint64_t) g32 * GL + lane;
     const bool valid = (uint32_t) lane < GL && ipos < A.n;
-    const uint32_t ip = A.order ? (valid ? A.order[ipos] : 0u) : (uint32_t) ipos;
-    int32_t qx = 0, qy = 0;
-    if (valid) {
-      typedef long long ll2_t __attribute__((ext_vector_type(2)));
-      const ll2_t p = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip);
-      qx = quant(p.x);
-      qy = quant(p.y);
-    }
+    // (an idle lane reads the last point: no load under a per-lane branch, so the point and the root's boxes -- which do
+    //  not depend on it -- are one memory round trip, not two)
+    const uint64_t ipc = valid ? ipos : A.n - 1;
+    const uint32_t ip = A.order ? A.order[ipc] : (uint32_t) ipc;
+    typedef long long ll2_t __attribute__((ext_vector_type(2)));
+    const ll2_t pt_raw = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip);
+    const QBox root_box = T.lvl[T.top][lane];
+    const uint64_t root_higher = sibling_order(T, T.top)[lane];
+    const int32_t qx = valid ? quant(pt_raw.x) : 0, qy = valid ? quant(pt_raw.y) : 0;
     const bool live = valid && ray_has_sky(sky, qx, qy);  // (above the map's skyline: a certain miss, no traversal)
     const int32_t qym1 = qy > 0 ? qy - 1 : 0;
     int32_t gx0 = live ? qx : kEmptyMin, gx1 = live ? qx : kEmptyMax, gy0 = live ? qy : kEmptyMin;
@@ -1652,8 +1695,8 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     int sp = 0, sp_max = 0;
     bool ovf = false;  // wave-uniform: the stack would not hold this group's traversal
     {
-      const QBox b = T.lvl[T.top][lane];
-      const uint64_t higher = sibling_order(T, T.top)[lane];
+      const QBox b = root_box;
+      const uint64_t higher = root_higher;
       uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
       if (__popcll(m) > stack_cap) { m = 0; ovf = true; }
       if ((m >> lane) & 1)
@@ -1778,11 +1821,15 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
     // settled: nothing above the point, or exactly one candidate and it is a certain hit (every other
     // edge over this x was pruned because it starts above that candidate's box top)
     const bool done = valid && !ovf && (cand_at == cand_base || sure_y0 != INT32_MIN);
-    if (done) {
-      const bool hit = cand_at != cand_base;
+    {  // (both gathers requested before either is stored; a lane without a hit reads slot 0)
+      const bool hit = done && cand_at != cand_base;
       const uint32_t slot = hit ? cand[lane] : 0u;
-      __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip);
-      if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip);
+      const uint32_t e = T.seid[slot];
+      const int32_t f = A.face ? T.sface[slot] : 0;
+      if (done) {
+        __builtin_nontemporal_store(hit ? e : 0xFFFFFFFFu, A.closest + ip);
+        if (A.face) __builtin_nontemporal_store(hit ? f : 0, A.face + ip);
+      }
     }
     // the others leave with their candidate list (the exact kernel needs nothing else: every edge that could be the
     // answer is on it, pruning only ever used certain hits) -- or, with an overflowed list, as a point for k_pip.
@@ -1839,12 +1886,14 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
 // of whose lanes wants a leaf block skips it (wave-uniform).  Same stack, twice the candidate lists; the hand-over
 // (one todo slot per position, one mask per 64 positions, the rest list) is exactly k_pip_walk's, so k_pip_exact
 // cannot tell the two apart.  Requires group_lanes == 64 (a large query set).
-__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256 * 2; }
+// (P points per lane: 2, or 4 -- 256 positions per wave, the traversal's own costs shared by twice the points)
+__host__ __device__ __forceinline__ size_t walk2_wave_lds(int top, int P = 2) { return (size_t) 16 * walk_stack_entries(top) + (size_t) kWalkList * 256 * P; }
 
 // (96 SGPRs: above that the hardware admits one block per CU fewer than the occupancy query reports, and the shared
 //  schedule's walk + k_lsi2 blocks per CU no longer fit -- the skyline pointer took it to 100: 0.785 -> 0.852 ms.
 //  256 threads x 9 blocks: the compiler then aims below 57 VGPRs -- at 56, six blocks fit beside two of k_lsi2's 80)
-__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk2(PipArgs A) {
+template <bool STATS, int P>
+__device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
   extern __shared__ uint4 walk_smem[];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
@@ -1852,10 +1901,11 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
   const uint32_t* const sky = (T.sky && T.sky[kSkyBuckets] == 0u) ? T.sky : nullptr;  // (exhaustive, or not used)
   const int stack_entries = walk_stack_entries(T.top);
   const int stack_cap = A.walk_stack > 0 && A.walk_stack < stack_entries ? A.walk_stack : stack_entries;
-  uint4* const stack = walk_smem + (size_t) wib * (walk2_wave_lds(T.top) / 16);
-  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_entries);  // [2][kWalkList][64], bank = lane
+  uint4* const stack = walk_smem + (size_t) wib * (walk2_wave_lds(T.top, P) / 16);
+  uint32_t* const cand = reinterpret_cast<uint32_t*>(stack + stack_entries);  // [P][kWalkList][64], bank = lane
   const uint32_t stack_lds = (uint32_t) (uintptr_t) stack;
-  const uint64_t ngroups = (A.n + 127) / 128;
+  constexpr uint32_t GP = 64u * P;  // positions per wave-group
+  const uint64_t ngroups = (A.n + GP - 1) / GP;
   const uint32_t nchunks = (uint32_t) ((ngroups + A.chunk_groups - 1) / A.chunk_groups);
   int part = blockIdx.x & 7, tried = 0;
   __shared__ unsigned long long ranges[4];
@@ -1863,24 +1913,37 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
   if (blockIdx.x == 0 && threadIdx.x < 8) A.next_work_counter[threadIdx.x * 32] = 0;  // (see k_lsi)
   if (blockIdx.x == 0 && threadIdx.x == 8) *A.next_rest_count = 0;
   __syncthreads();
+  // STATS (the instrumented build, rj_set_option "stats" 1 + "pip_walk" 2): what a 128-position group costs, per wave
+  unsigned long long st_pops = 0, st_stale = 0, st_nodes = 0, st_leaf = 0, st_setvisits = 0, st_steps = 0, st_pushed = 0, st_sweeps = 0, st_swept = 0,
+                     st_groups = 0, st_want = 0, st_hits = 0, st_rest = 0;
   for (;;) {
     uint32_t g32 = 0;
     if (!next_group<4>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
     typedef long long ll2_t __attribute__((ext_vector_type(2)));
-    int32_t qx[2], qy[2], qbest[2], sure_y0[2];
-    uint32_t cand_base[2], cand_at[2];
-    bool valid[2];
+    int32_t qx[P], qy[P], qbest[P], sure_y0[P];
+    uint32_t cand_base[P], cand_at[P];
+    bool valid[P];
+    // Every load the group starts with is requested before the first one is waited for: the P points (positions past the
+    // end read the last point: no branch around a load, so the compiler batches them) and the root's boxes, which do not
+    // depend on the points at all.  Left in `if (valid)` regions each load was waited for inside its own region: three
+    // memory round trips before the first test, of the 23 k cycles a group's critical path is long.
+    uint32_t ipl[P];
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-      const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
+    for (int p = 0; p < P; p++) {
+      const uint64_t ipos = (uint64_t) g32 * GP + (uint64_t) p * 64 + lane;
       valid[p] = ipos < A.n;
-      const uint32_t ip = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
-      qx[p] = 0; qy[p] = 0;
-      if (valid[p]) {
-        const ll2_t pt = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ip);
-        qx[p] = quant(pt.x);
-        qy[p] = quant(pt.y);
-      }
+      const uint64_t ipc = valid[p] ? ipos : A.n - 1;
+      ipl[p] = A.order ? A.order[ipc] : (uint32_t) ipc;
+    }
+    ll2_t ptl[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) ptl[p] = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ipl[p]);
+    const QBox root_box = T.lvl[T.top][lane];
+    const uint64_t root_higher = sibling_order(T, T.top)[lane];
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      qx[p] = valid[p] ? quant(ptl[p].x) : 0;
+      qy[p] = valid[p] ? quant(ptl[p].y) : 0;
       qbest[p] = valid[p] ? 0x7FFFFFFF : -1;
       cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
       cand_at[p] = cand_base[p];
@@ -1889,7 +1952,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
     // (above the map's skyline: a certain miss -- the point sits the traversal out like a position past the end)
     if (sky) {
 #pragma unroll
-      for (int p = 0; p < 2; p++)
+      for (int p = 0; p < P; p++)
         if (sky[(uint32_t) qx[p] >> kSkyShift] <= (uint32_t) qy[p]) qbest[p] = -1;
     }
     int32_t gx0, gx1, gy0;
@@ -1899,6 +1962,12 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
       const int32_t b0 = l0 ? qx[0] : kEmptyMax, b1 = l1 ? qx[1] : kEmptyMax;
       const int32_t c0 = l0 ? qy[0] : kEmptyMin, c1 = l1 ? qy[1] : kEmptyMin;
       gx0 = a0 < a1 ? a0 : a1; gx1 = b0 > b1 ? b0 : b1; gy0 = c0 < c1 ? c0 : c1;
+#pragma unroll
+      for (int p = 2; p < P; p++) {
+        const bool lp = qbest[p] >= 0;
+        const int32_t ap = lp ? qx[p] : kEmptyMin, bp = lp ? qx[p] : kEmptyMax, cp = lp ? qy[p] : kEmptyMin;
+        gx0 = gx0 < ap ? gx0 : ap; gx1 = gx1 > bp ? gx1 : bp; gy0 = gy0 < cp ? gy0 : cp;
+      }
     }
     wave_min_max_min(gx0, gx1, gy0);
     int32_t gbest = 0x7FFFFFFF;  // wave max of both sets' qbest
@@ -1911,35 +1980,46 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         um &= um - 1;
         const int32_t cx0 = bcast(b.x0, c), cy0 = bcast(b.y0, c);
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
-        if (__ballot(ray_can_hit(qx[0], qy[0] > 0 ? qy[0] - 1 : 0, qbest[0], cx0, cy0, cx1, cy1) || ray_can_hit(qx[1], qy[1] > 0 ? qy[1] - 1 : 0, qbest[1], cx0, cy0, cx1, cy1)))
-          keep |= 1ull << c;
+        bool any = ray_can_hit(qx[0], qy[0] > 0 ? qy[0] - 1 : 0, qbest[0], cx0, cy0, cx1, cy1) || ray_can_hit(qx[1], qy[1] > 0 ? qy[1] - 1 : 0, qbest[1], cx0, cy0, cx1, cy1);
+#pragma unroll
+        for (int p = 2; p < P; p++) any = any || ray_can_hit(qx[p], qy[p] > 0 ? qy[p] - 1 : 0, qbest[p], cx0, cy0, cx1, cy1);
+        if (__ballot(any)) keep |= 1ull << c;
       }
       return keep;
     };
     int sp = 0;
     bool ovf = false;  // wave-uniform: the stack would not hold this group's traversal
     {
-      const QBox b = T.lvl[T.top][lane];
-      const uint64_t higher = sibling_order(T, T.top)[lane];
+      const QBox b = root_box;
+      const uint64_t higher = root_higher;
       uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1));
       if (__popcll(m) > stack_cap) { m = 0; ovf = true; }
       if ((m >> lane) & 1)
         stack[__popcll(m & higher)] = make_uint4(((uint32_t) T.top << 28) | (uint32_t) lane, (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
       sp = __popcll(m);
       wave_lds_fence();
+      if (STATS) { st_groups++; st_pushed += (unsigned long long) sp; }
     }
     while (sp > 0) {
       --sp;
       uint4 ent;
+      if (STATS) st_pops++;
       asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(ent) : "v"(stack_lds + (uint32_t) sp * 16u) : "memory");
       const int32_t ey0 = (int32_t) ent.y, ex0 = (int32_t) ent.z, ex1 = (int32_t) ent.w;
       // (compares, not sign bits: 3 VALU + 1 SALU per set where the sign test took 5 VALU, and 15 of a group's 25 pops
       //  end right here)
       const uint32_t ew = (uint32_t) (ex1 - ex0);
-      bool want[2];
+      bool want[P];
+      bool want_any = false;
 #pragma unroll
-      for (int p = 0; p < 2; p++) want[p] = ((uint32_t) (qx[p] - ex0) <= ew) & (qbest[p] >= ey0);
-      if (!__ballot(want[0] || want[1])) continue;  // stale: untouched
+      for (int p = 0; p < P; p++) {
+        want[p] = ((uint32_t) (qx[p] - ex0) <= ew) & (qbest[p] >= ey0);
+        want_any = want_any || want[p];
+      }
+      if (!__ballot(want_any)) {  // stale: untouched
+        if (STATS) st_stale++;
+        continue;
+      }
       const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
@@ -1955,7 +2035,9 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
               make_uint4(((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane), (uint32_t) b.y0, (uint32_t) b.x0, (uint32_t) b.x1);
         sp += __popcll(m);
         wave_lds_fence();
+        if (STATS) { st_nodes++; st_pushed += (unsigned long long) __popcll(m); }
       } else {
+        if (STATS) st_leaf++;
         const uint32_t slot0 = idx * 64;
         // (the lane offset passes through an empty asm: left alone the compiler keeps base + 16 lane and base + 8 lane of
         //  the two arrays in four VGPRs through the whole traversal, and the kernel needs its 56)
@@ -1967,8 +2049,9 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
         bool changed = false;
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
+        for (int p = 0; p < P; p++) {
           if (!__ballot(want[p])) continue;  // none of this set's points is under this block
+          if (STATS) { st_setvisits++; st_want += (unsigned long long) __popcll(__ballot(want[p])); }
           const uint32_t bk = want[p] ? ((uint32_t) qx[p] - sx0s) >> sh : 0u;
           const uint32_t bsh = (bk & 3u) * 8u;
           const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
@@ -1984,6 +2067,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
           jlo = want[p] ? jlo : 0;
           const int32_t qbest_before = qbest[p];
           auto scan_step = [&]() {
+                  if (STATS) st_steps++;
             const int jj = j & 63;
             const int ja = j << 2;
             const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, bb.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, bb.x1);
@@ -1993,6 +2077,7 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
               const bool replace = certain && sy1 < sure_y0[p];
               const bool first = cand_at[p] == cand_base[p];
               const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
+              if (STATS && lane == __builtin_ctzll(__ballot(true))) st_hits++;
               cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot0 + (uint32_t) jj;
               sure_y0[p] = (replace || (first && certain)) ? sy0 : INT32_MIN;
               cand_at[p] += replace ? 0u : 64u;
@@ -2011,9 +2096,13 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         }
         if (__ballot(changed)) {
           const int32_t gbest_before = gbest;
-          gbest = wave_max(qbest[0] > qbest[1] ? qbest[0] : qbest[1]);
+          int32_t lane_best = qbest[0] > qbest[1] ? qbest[0] : qbest[1];
+#pragma unroll
+          for (int p = 2; p < P; p++) lane_best = lane_best > qbest[p] ? lane_best : qbest[p];
+          gbest = wave_max(lane_best);
           if (gbest < gbest_before && sp > 1) {  // sweep the stack once: drop every entry that starts above the group's bound
             int kept = 0;
+            if (STATS) st_sweeps++;
             for (int base = 0; base < sp; base += 64) {
               const int i = base + lane;
               const bool have = i < sp;
@@ -2025,31 +2114,40 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
               if (alive) stack[kept + rank_below(am)] = en;
               kept += __popcll(am);
             }
+            if (STATS) st_swept += (unsigned long long) (sp - kept);
             sp = kept;
             wave_lds_fence();
           }
         }
       }
     }
-    // hand-over, per set: exactly k_pip_walk's
+    // hand-over, per set: exactly k_pip_walk's.  The gathers of the settled points -- edge id and face id under the one
+    // candidate -- are all requested first (a lane without a hit reads slot 0: no branch around a load) and stored last,
+    // behind the lists and masks: one memory round trip at the end of a group instead of 2 P.
+    uint32_t out_e[P], ipv[P];
+    int32_t out_f[P];
+    bool donev[P];
 #pragma unroll
-    for (int p = 0; p < 2; p++) {
-      const uint64_t ipos = (uint64_t) g32 * 128 + (uint64_t) p * 64 + lane;
+    for (int p = 0; p < P; p++) {
+      const uint64_t ipos = (uint64_t) g32 * GP + (uint64_t) p * 64 + lane;
       // (the point's index is read again rather than held in a register through the traversal: the kernel keeps to 56
       //  VGPRs, six of its blocks fit beside two of k_lsi2)
-      const uint32_t ip = A.order ? (valid[p] ? A.order[ipos] : 0u) : (uint32_t) ipos;
-      const bool done = valid[p] && !ovf && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
-      if (done) {
-        const bool hit = cand_at[p] != cand_base[p];
-        const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
-        __builtin_nontemporal_store(hit ? T.seid[slot] : 0xFFFFFFFFu, A.closest + ip);
-        if (A.face) __builtin_nontemporal_store(hit ? T.sface[slot] : 0, A.face + ip);
-      }
+      ipv[p] = A.order ? A.order[valid[p] ? ipos : A.n - 1] : (uint32_t) ipos;
+      donev[p] = valid[p] && !ovf && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
+      const bool hit = donev[p] && cand_at[p] != cand_base[p];
+      const uint32_t slot = hit ? cand[cand_base[p]] : 0u;
+      const uint32_t e = T.seid[slot];
+      const int32_t f = A.face ? T.sface[slot] : 0;
+      out_e[p] = hit ? e : 0xFFFFFFFFu;
+      out_f[p] = hit ? f : 0;
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
-      const bool listed = valid[p] && !done && !ovf && fill <= (uint32_t) kWalkList;
-      const bool rest = valid[p] && !done && !listed;
+      const bool listed = valid[p] && !donev[p] && !ovf && fill <= (uint32_t) kWalkList;
+      const bool rest = valid[p] && !donev[p] && !listed;
       const uint64_t lm = __ballot(listed);
-      const uint64_t g64 = (uint64_t) g32 * 2 + p;  // the 64-position group this set is
+      const uint64_t g64 = (uint64_t) g32 * P + p;  // the 64-position group this set is
       if (listed) {
         const uint64_t rec = g64 * 64 + rank_below(lm);  // (records side by side at the head of the group's region: k_pip_walk)
 #pragma unroll
@@ -2061,12 +2159,47 @@ __global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) void k
         unsigned long long base = 0;
         if (lane == 0) base = atomicAdd(A.rest_count, (unsigned long long) __popcll(rm));
         base = ((unsigned long long) __builtin_amdgcn_readfirstlane((uint32_t) (base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t) base);
-        if (rest) A.rest[base + rank_below(rm)] = ip;
+        if (rest) A.rest[base + rank_below(rm)] = ipv[p];
+      }
+      if (STATS) st_rest += (unsigned long long) __popcll(rm);
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+      if (donev[p]) {
+        __builtin_nontemporal_store(out_e[p], A.closest + ipv[p]);
+        if (A.face) __builtin_nontemporal_store(out_f[p], A.face + ipv[p]);
       }
     }
     wave_lds_fence();  // (the lists are reused by the next group)
   }
+  if (STATS && A.stats) {
+    // (per lane: st_hits is counted by one lane of each hit; everything else is wave-uniform and reported by lane 0)
+    const unsigned long long hits = st_hits;
+    if (hits) atomicAdd(&A.stats[6], hits);
+    if (lane == 0) {
+      atomicAdd(&A.stats[0], st_leaf);        // leaf blocks opened (per 128-position group traversal)
+      atomicAdd(&A.stats[1], st_rest);
+      atomicAdd(&A.stats[2], st_nodes);       // nodes expanded
+      atomicAdd(&A.stats[3], st_steps);       // scan steps (per set)
+      atomicAdd(&A.stats[4], st_groups);      // 128-position groups
+      atomicAdd(&A.stats[5], st_setvisits);   // (leaf, set) visits with a wanting lane
+      atomicAdd(&A.stats[7], st_sweeps);
+      atomicAdd(&A.stats[8], st_swept);       // entries the sweeps dropped
+      atomicAdd(&A.stats[10], st_pops);
+      atomicAdd(&A.stats[11], st_pushed);
+      atomicAdd(&A.stats[13], st_stale);      // pops no lane could use
+      atomicAdd(&A.stats[15], st_want);       // lanes that wanted their (leaf, set) visit
+    }
+  }
 }
+
+
+// The kernels of the body above.  k_pip_walk2 is held to 56 VGPRs (the attribute takes a literal, hence no template): six
+// of its blocks fit beside two of k_lsi2's 80 on a SIMD's 512.
+__global__ __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(96))) __attribute__((amdgpu_num_vgpr(28))) void k_pip_walk2(PipArgs A) { pip_walk_many<false, 2>(A); }
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk2_stats(PipArgs A) { pip_walk_many<true, 2>(A); }
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk4(PipArgs A) { pip_walk_many<false, 4>(A); }
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_sgpr(96))) void k_pip_walk4_stats(PipArgs A) { pip_walk_many<true, 4>(A); }
 
 
 // The walk's leftovers: the exact predicate (pip.h:36-95, as in k_pip's evaluate) over each listed point's complete
@@ -2445,43 +2578,56 @@ hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int 
   return hipGetLastError();
 }
 
-int pip_walk2_blocks_per_cu(int top) {
-  const size_t block = 4 * walk2_wave_lds(top) + 64;
+int pip_walk2_blocks_per_cu(int top, int points) {
+  const size_t block = 4 * walk2_wave_lds(top, points == 4 ? 4 : 2) + 64;
   const size_t by_lds = (size_t) 160 * 1024 / block;
-  return (int) (by_lds < 8 ? by_lds : 8);
+  const size_t cap = points == 4 ? 4 : 8;  // (k_pip_walk2<*, 4> is built for four blocks per CU: its registers)
+  return (int) (by_lds < cap ? by_lds : cap);
 }
 
 // ... beside `lsi_blocks_per_cu` resident blocks of k_lsi (17.5 KiB of LDS and one wave slot per SIMD each)
-int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu) {
-  const size_t block = 4 * walk2_wave_lds(top) + 64;
+int pip_walk2_blocks_beside(int top, int lsi_blocks_per_cu, int points) {
+  const int P = points == 4 ? 4 : 2;
+  const size_t block = 4 * walk2_wave_lds(top, P) + 64;
   const size_t left = (size_t) 160 * 1024 > (size_t) lsi_blocks_per_cu * 17920 ? (size_t) 160 * 1024 - (size_t) lsi_blocks_per_cu * 17920 : 0;
   int n = (int) (left / block);
   if (n > 8 - lsi_blocks_per_cu) n = 8 - lsi_blocks_per_cu;
   // ... and of a SIMD's 512 VGPRs 80 per wave of k_lsi2 and 56 per wave of the walk (it is kept to that: the point
   // indices are read again at the end, base + lane addresses are not held): 6 beside 2.  (At 64 it was 5 beside 2.
   // Tried: k_lsi2 held to 64 VGPRs instead -- 14 spilled registers make it 48 % slower.)
-  static int walk_regs = 0, lsi_regs = 0;
-  if (!walk_regs) {
+  static int walk_regs[2] = {0, 0}, lsi_regs = 0;
+  if (!walk_regs[0]) {
     hipFuncAttributes fa;
-    walk_regs = hipFuncGetAttributes(&fa, (const void*) k_pip_walk2) == hipSuccess && fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 64;
+    walk_regs[0] = hipFuncGetAttributes(&fa, (const void*) k_pip_walk2) == hipSuccess && fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 64;
+    walk_regs[1] = hipFuncGetAttributes(&fa, (const void*) k_pip_walk4) == hipSuccess && fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 96;
     lsi_regs = hipFuncGetAttributes(&fa, (const void*) k_lsi2) == hipSuccess && fa.numRegs > 0 ? (fa.numRegs + 7) / 8 * 8 : 80;
   }
-  const int by_vgpr = (512 - lsi_blocks_per_cu * lsi_regs) / walk_regs;
+  const int by_vgpr = (512 - lsi_blocks_per_cu * lsi_regs) / walk_regs[P == 4];
   if (n > by_vgpr) n = by_vgpr;
-  if (n > pip_walk2_blocks_per_cu(top)) n = pip_walk2_blocks_per_cu(top);
+  if (n > pip_walk2_blocks_per_cu(top, P)) n = pip_walk2_blocks_per_cu(top, P);
   return n < 1 ? 1 : n;
 }
 
-hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a_in, int max_blocks, int cus) {
+hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a_in, int max_blocks, int cus, bool stats, int points) {
   PipArgs a = a_in;
-  const size_t lds = 4 * walk2_wave_lds(a.bvh.top);
-  const int res = cus * pip_walk2_blocks_per_cu(a.bvh.top);
-  a.group_lanes = 64;  // (positions per mask; a wave takes two of them)
-  const uint64_t ngroups = (a.n + 127) / 128;
-  a.chunk_groups = a.chunk_groups ? a.chunk_groups : 3;  // (128-point groups: the same 6 x 64 positions per chunk)
+  const int P = points == 4 ? 4 : 2;
+  const size_t lds = 4 * walk2_wave_lds(a.bvh.top, P);
+  const int res = cus * pip_walk2_blocks_per_cu(a.bvh.top, P);
+  a.group_lanes = 64;  // (positions per mask; a wave takes P of them)
+  const uint64_t ngroups = (a.n + 64 * P - 1) / (64 * P);
+  a.chunk_groups = a.chunk_groups ? a.chunk_groups : (P == 2 ? 3 : 2);  // (128-point groups: the same 6 x 64 positions per chunk; 256-point groups: 8 x 64)
   const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
-  hipLaunchKernelGGL(k_pip_walk2, dim3(grid), dim3(256), lds, st, a);
+  if (P == 4) {
+    if (stats)
+      hipLaunchKernelGGL(k_pip_walk4_stats, dim3(grid), dim3(256), lds, st, a);
+    else
+      hipLaunchKernelGGL(k_pip_walk4, dim3(grid), dim3(256), lds, st, a);
+  } else if (stats) {
+    hipLaunchKernelGGL(k_pip_walk2_stats, dim3(grid), dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL(k_pip_walk2, dim3(grid), dim3(256), lds, st, a);
+  }
   return hipGetLastError();
 }
 
