@@ -349,6 +349,17 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  *   "comm_ranks"                                                the ranks RCCL counts in the handle's communicator (0: none) */
 int rj_set_option(rj_handle h, const char* name, int64_t value);
 int rj_get_option(rj_handle h, const char* name, int64_t* value);
+/* rj_get_plan: what the handle ran for the last query of each kind and on what grounds, as ONE JSON object (text):
+ *   "epoch"     counts the events after which the handle decides again -- rj_upload_map, rj_build_lbvh, another query size,
+ *               "pip_concurrent"; every record below carries the epoch it was made in ("current": still that epoch)
+ *   "index"     per map: levels, slots, what a leaf is, skyline, column index
+ *   "schedule"  of an LSI + PIP pair: the choice ("turns" / "shared" / "full grids" / "undecided"), the trials run, the best
+ *               span per schedule, the epoch it was settled in and whether it is in force, the shared grids
+ *   "lsi", "records", "pip"   kernel, grid, queries per lane, stream, processing order, passes, and -- where the
+ *               handle took another path than the default -- why
+ * Once settled a decision stays until the epoch moves.  Host-side state only: no synchronisation, no launch.  The text
+ * is written to buf (NUL-terminated, truncated to cap) and its full length to *need; either may be NULL / 0. */
+int rj_get_plan(rj_handle h, char* buf, size_t cap, size_t* need);
 /* Experiment knobs for tools/ and the fault-path tests -- grids, chunk sizes, run lengths ("chunk_groups",
  * "group_lanes", "max_blocks", "lsi_share_blocks", "pip_share_blocks", "stack_cap", "walk_stack", "strip_shift", "run_cap", "pack_solo",
  * "pack_spread"; rj_api.hip lists their ranges).  Not needed by a host of the library, never a correctness input,

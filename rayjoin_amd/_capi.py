@@ -72,6 +72,7 @@ SYMBOLS = {
     "rj_set_debug_option": (_int, [_vp, C.c_char_p, _i64]),
     "rj_get_debug_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
     "rj_get_option": (_int, [_vp, C.c_char_p, C.POINTER(_i64)]),
+    "rj_get_plan": (_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "rj_dev_alloc": (_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     "rj_dev_free": (_int, [_vp, _vp]),
     "rj_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -427,6 +428,15 @@ class Handle:
         buf = (C.c_float * 12)()
         self._check(self.L.rj_last_ms_all(self.h, buf, 12))
         return list(buf)
+
+    def get_plan(self):
+        """rj_get_plan: what the last query of each kind ran and why (a dict)"""
+        import json
+        need = C.c_size_t(0)
+        self._check(self.L.rj_get_plan(self.h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        self._check(self.L.rj_get_plan(self.h, buf, need.value + 1, None))
+        return json.loads(buf.value.decode())
 
     def last_stats_raw(self):
         """the 16 counters as a list (what each slot means depends on the instrumented kernel that ran: rj_kernels.hip)"""

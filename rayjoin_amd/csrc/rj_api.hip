@@ -113,7 +113,8 @@ struct rj_handle_s {
   int co_mode = 0;            // schedule of the pair in flight
   bool co_measure = false;    // the pair in flight is complete (LSI + PIP): its span can be read
   bool co_points = false;     // ... and k_lsi_points ran between them
-  uint64_t co_n = 0;          // query size the decision was made for
+  uint64_t co_n = 0;          // query size the decision was made for (LSI segments)
+  uint64_t co_np = 0;         // ... and the PIP side's (points)
   // how the chip is split when shared.  Both kernels are persistent, so what counts is what fits a CU together: the
   // register file takes 6 walk blocks + 2 k_lsi blocks, and that is where the step is shortest wherever the walk may keep
   // 8 blocks per CU (tree of <= 4 levels); where LDS limits it to 7 (5 levels) the best k_lsi grid is half a block per CU
@@ -267,6 +268,23 @@ struct rj_handle_s {
   uint64_t ag_send_words = 0, ag_recv_words = 0;
   int nranks = 1, rank = 0;
   unsigned long long* d_counts = nullptr;  // [nranks] gathered counts
+  // rj_get_plan: what the last query of each kind ran, on what grid, and on what grounds.  `epoch` counts the events that
+  // make the handle decide again -- a map upload, an index build, another query size, "pip_concurrent" -- and every record
+  // carries the epoch it was made in: a decision older than the handle's epoch is not in force any more.
+  struct PlanRec {
+    uint64_t epoch = 1;
+    uint64_t sched_epoch = 0;  // the epoch in which the schedule in force (co_choice) was settled
+    struct Lsi { bool ran = false; uint64_t epoch = 0, n = 0; LaunchNote k = {"", 0, 0}; int order = 0, co_mode = 0; bool paired = false, shared = false; } lsi;
+    struct Rec { bool ran = false; uint64_t epoch = 0; bool two_kernels = false, count_on_device = false; uint64_t seen = ~0ull; } rec;
+    struct Pip {
+      bool ran = false, aux = false, caller = false, shared = false;
+      uint64_t epoch = 0, n = 0, rest_hint = ~0ull;
+      LaunchNote first = {"", 0, 0};
+      int passes = 0, order = 0, exact_blocks = 0, locate_blocks = 0;
+      const char* why = "";
+    } pip;
+  } plan;
+  std::string plan_text;
   std::string err;
 };
 
@@ -358,7 +376,8 @@ hipError_t join_aux(rj_handle h) {
 
 // ---- "pip_concurrent" 2: which schedule for this pair? ------------------------------------------
 static void co_reset(rj_handle h) {
-  h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0;
+  h->plan.epoch++;  // (every decision taken so far is void: rj_get_plan)
+  h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0; h->co_np = 0;
   h->co_ratio = 0.46f;
   h->co_L = h->co_best_L = 0;
 }
@@ -401,6 +420,7 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
     h->co_choice = 0;
     for (int m = 1; m < 3; m++) if (h->co_best[m] < h->co_best[h->co_choice]) h->co_choice = m;
     if (h->co_best_L) h->co_L = h->co_best_L;  // (the split of the best shared pair stays)
+    h->plan.sched_epoch = h->plan.epoch;
   }
 }
 static int co_pick(rj_handle h, uint64_t n) {
@@ -615,6 +635,89 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "lsi_share_blocks")) *value = h->lsi_share_blocks();
   else if (!strcmp(name, "pip_share_blocks")) *value = h->last_pip_share ? h->last_pip_share : h->pip_share_blocks();
   else return fail(h, RJ_E_INVALID, "unknown option '%s'", name);
+  return RJ_OK;
+}
+
+// rj_get_plan: one JSON object (text) -- what the last query of each kind ran and why.  Host-side state only: nothing is
+// synchronised or launched.
+int rj_get_plan(rj_handle h, char* buf, size_t cap, size_t* need) {
+  RJ_CHECK_H(h);
+  const rj_handle_s::PlanRec& P = h->plan;
+  char t[1024];
+  std::string o = "{";
+  auto add = [&](const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t, sizeof(t), fmt, ap);
+    va_end(ap);
+    o += t;
+  };
+  static const char* const kOrder[3] = {"as given", "through a cached Morton permutation", "through a Morton permutation sorted in this call (runs alone)"};
+  static const char* const kSched[3] = {"turns", "shared", "full grids"};
+  add("\"epoch\": %llu", (unsigned long long) P.epoch);
+  add(", \"index\": [");
+  for (int m = 0; m < 2; m++) {
+    const BvhState& b = h->bvh[m];
+    add("%s{\"map\": %d, \"built\": %s, \"levels\": %d, \"slots\": %llu, \"leaves\": \"%s\", \"skyline\": %s, \"columns\": %s, \"column_shift\": %d}",
+        m ? ", " : "", m, b.built ? "true" : "false", b.top, (unsigned long long) b.n0p, b.leaf_order == 1 ? "polyline runs" : "Hilbert neighbours",
+        b.use_sky ? "true" : "false", b.strips_built ? "true" : "false", b.strips_built ? b.strip_shift : 0);
+  }
+  add("]");
+  // the schedule of an LSI + PIP pair
+  add(", \"schedule\": {\"pip_concurrent\": %d, \"trials\": %d, \"of\": %d", h->pip_concurrent, h->co_trials, kCoTrials);
+  if (h->pip_concurrent == 2) {
+    add(", \"choice\": \"%s\", \"settled\": %s, \"settled_in_epoch\": %llu, \"in_force\": %s, \"for_query_size\": %llu", h->co_choice >= 0 ? kSched[h->co_choice] : "undecided",
+        h->co_choice >= 0 ? "true" : "false", (unsigned long long) P.sched_epoch, h->co_choice >= 0 && P.sched_epoch == P.epoch ? "true" : "false",
+        (unsigned long long) h->co_n);
+    add(", \"best_span_us\": {");
+    for (int m = 0; m < 3; m++) add("%s\"%s\": %d", m ? ", " : "", kSched[m], h->co_best[m] < 1e29f ? (int) (h->co_best[m] * 1000.0f) : -1);
+    add("}, \"turns_ratio_lsi_over_pip\": %.3f", (double) h->co_ratio);
+  } else {
+    add(", \"choice\": \"%s\", \"settled\": true", h->pip_concurrent == 1 ? "shared" : "turns");
+  }
+  add(", \"shared_grids\": {\"lsi_blocks\": %d, \"pip_blocks\": %d, \"fixed_by_debug_option\": %s}}", h->lsi_share_blocks(),
+      h->last_pip_share ? h->last_pip_share : h->pip_share_blocks(), h->lsi_share_set || h->pip_share_set ? "true" : "false");
+  // the last LSI query
+  if (P.lsi.ran) {
+    add(", \"lsi\": {\"epoch\": %llu, \"current\": %s, \"segments\": %llu, \"kernel\": \"%s\", \"blocks\": %d, \"segments_per_lane\": %d, \"order\": \"%s\", "
+        "\"paired_with_pip\": %s, \"schedule\": \"%s\", \"on_shared_grid\": %s}",
+        (unsigned long long) P.lsi.epoch, P.lsi.epoch == P.epoch ? "true" : "false", (unsigned long long) P.lsi.n, P.lsi.k.kernel, P.lsi.k.grid, P.lsi.k.per_lane,
+        kOrder[P.lsi.order], P.lsi.paired ? "true" : "false", P.lsi.paired ? kSched[P.lsi.co_mode] : "alone (a synchronous or unpaired query: full grid)",
+        P.lsi.shared ? "true" : "false");
+  } else {
+    add(", \"lsi\": null");
+  }
+  if (P.rec.ran) {
+    add(", \"records\": {\"epoch\": %llu, \"kernels\": \"%s\", \"count\": \"%s\", \"pairs_expected\": %lld, \"rule\": \"%s\"}", (unsigned long long) P.rec.epoch,
+        P.rec.two_kernels ? "k_lsi_points + k_lsi_points_gcd over what it declines" : "k_lsi_points_gcd alone",
+        P.rec.count_on_device ? "read on the device" : "given by the caller", P.rec.seen == ~0ull ? -1ll : (long long) P.rec.seen,
+        h->points_split >= 0 ? "fixed by the lsi_points_split option" : "two kernels from 393216 pairs on (the count of the last query; unknown yet: two)");
+  } else {
+    add(", \"records\": null");
+  }
+  if (P.pip.ran) {
+    add(", \"pip\": {\"epoch\": %llu, \"current\": %s, \"points\": %llu, \"points_from\": \"%s\", \"stream\": \"%s\", \"on_shared_grid\": %s, \"order\": \"%s\", "
+        "\"passes\": %d, \"first_pass\": {\"kernel\": \"%s\", \"blocks\": %d, \"points_per_lane\": %d}",
+        (unsigned long long) P.pip.epoch, P.pip.epoch == P.epoch ? "true" : "false", (unsigned long long) P.pip.n, P.pip.caller ? "a caller-owned array" : "the query map's vertices",
+        P.pip.aux ? "second (beside the LSI query)" : "main", P.pip.shared ? "true" : "false", kOrder[P.pip.order], P.pip.passes, P.pip.first.kernel, P.pip.first.grid,
+        P.pip.first.per_lane);
+    if (P.pip.passes == 3)
+      add(", \"second_pass\": {\"kernel\": \"k_pip_exact\", \"blocks\": %d, \"locate_blocks\": %d}, \"left_over_by_last_query_of_this_size\": %lld", P.pip.exact_blocks,
+          P.pip.locate_blocks, P.pip.rest_hint == ~0ull ? -1ll : (long long) P.pip.rest_hint);
+    add(", \"why\": \"");
+    for (const char* c = P.pip.why; *c; c++) { if (*c == '"' || *c == '\\') o += '\\'; o += *c; }
+    add("\"}");
+  } else {
+    add(", \"pip\": null");
+  }
+  o += "}";
+  h->plan_text = o;
+  if (need) *need = o.size();
+  if (buf && cap) {
+    const size_t k = o.size() < cap - 1 ? o.size() : cap - 1;
+    memcpy(buf, o.data(), k);
+    buf[k] = 0;
+  }
   return RJ_OK;
 }
 
@@ -1332,6 +1435,10 @@ static int lsi_launch(rj_handle h, int base_map_id, int query_map_id, uint64_t q
   if (qe > qb) {
     RJ_HIP(h, launch_lsi(h->stream, a, h->stats_on, max_blocks, h->lsi_segments, &h->last_lsi_segments));
     h->flip_lsi = 1 - flip;
+    rj_handle_s::PlanRec::Lsi& pl = h->plan.lsi;
+    pl.ran = true; pl.epoch = h->plan.epoch; pl.n = qe - qb; pl.k = last_launch();
+    pl.order = order ? (h->order_fresh ? 2 : 1) : 0;
+    pl.paired = pairable; pl.co_mode = h->co_mode; pl.shared = h->lsi_shared;
   } else {
     RJ_HIP(h, hipMemsetAsync(a.counter, 0, 8, h->stream));  // (an empty query: nothing ran that could have counted)
   }
@@ -1431,6 +1538,8 @@ static hipError_t lsi_points_on_stream(rj_handle h, const uint32_t* pairs_dev, u
                                    h->d_counter + kSlowCountWord + f, h->d_counter + kSlowCountWord + (1 - f), h->d_rest + 2);
   if (list) h->flip_slow = 1 - f;
   h->last_points_split = list ? 1 : 0;
+  h->plan.rec.ran = true; h->plan.rec.epoch = h->plan.epoch; h->plan.rec.two_kernels = list != nullptr;
+  h->plan.rec.count_on_device = n_dev != nullptr; h->plan.rec.seen = seen;
   return e;
 }
 
@@ -1520,6 +1629,17 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
   h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !(order && h->order_fresh) && !h->stats_on && n > 0;
+  if (h->co_measure) {
+    // (a pair with another point count is another workload: the schedule is decided again from the next pair on --
+    //  the pair in flight keeps the grids its LSI side was launched with)
+    if (h->co_np && (n > h->co_np + h->co_np / 4 || n + n / 4 < h->co_np)) {
+      const int keep_mode = h->co_mode;
+      co_reset(h);
+      h->co_mode = keep_mode;
+      h->co_measure = false;  // (its span belongs to neither workload's trials)
+    }
+    h->co_np = n;
+  }
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
   // in flight together (calls on ONE stream are ordered by the stream)
@@ -1568,7 +1688,11 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // "auto" drops the first pass where it does not pay: most points left over, or many overflowed lists in absolute
   // terms -- k_pip locates those one scattered handful per wave (the list is in no useful order), which on the gaussian
   // polygons (25 k of 8 M) costs more than the walk saves
-  if (walk && h->pip_walk == 1 && seen != ~0ull && (seen * 10 > n * 3 || seen > 16384)) walk = false;
+  const char* why = !h->pip_walk ? "\"pip_walk\" 0: the exact kernel alone" : (walk ? "" : "instrumented (\"stats\"), no points, or more than 2^32 of them: the exact kernel alone");
+  if (walk && h->pip_walk == 1 && seen != ~0ull && (seen * 10 > n * 3 || seen > 16384)) {
+    walk = false;
+    why = "the last two-pass query of this size left too many points to the exact kernel (> 30 %, or > 16384): first pass dropped";
+  }
   if (walk && h->rest_cap[si] < n) {
     // (both streams' lists at once, the first time a size is seen: a later query on the other stream -- the shared
     //  schedule's trial pair -- must not pay for an allocation inside its measured span)
@@ -1628,6 +1752,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
       RJ_HIP(h, launch_pip_walk(st, w, h->stats_on, walk_blocks));
     }
     if (aux && h->lsi_shared) h->last_pip_share = walk_blocks;
+    h->plan.pip.first = columns ? last_strip_launch() : last_launch();
     toc(h, RJ_T_PIP_WALK, st);
     h->flip_walk[si] = 1 - wflip;
     // second pass: the exact predicate over the candidate lists, and -- the kernel's first blocks -- k_pip's traversal
@@ -1653,9 +1778,20 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     h->walk_n[si] = n;
     RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8, r));
     h->flip_pip[si] = 1 - pflip;
+    h->plan.pip.exact_blocks = h->cus * 8; h->plan.pip.locate_blocks = rest_blocks;
+    if (columns) why = "the base map has a column index (a map of closed rings): the first pass reads the point's strip";
+    else if (!two && h->walk_points >= 2) why = "one point per lane: a query set too small for full groups on every resident wave (or a debug knob set)";
   } else if (n) {
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
     h->flip_pip[aux ? 1 : 0] = 1 - pflip;
+    h->plan.pip.first = last_launch();
+    h->plan.pip.exact_blocks = h->plan.pip.locate_blocks = 0;
+  }
+  {
+    rj_handle_s::PlanRec::Pip& pp = h->plan.pip;
+    pp.ran = n > 0; pp.epoch = h->plan.epoch; pp.n = n; pp.aux = aux; pp.caller = pts_dev != nullptr;
+    pp.shared = aux && h->lsi_shared; pp.passes = h->last_passes; pp.rest_hint = seen; pp.why = why;
+    pp.order = order ? (h->order_fresh ? 2 : 1) : 0;
   }
   toc(h, RJ_T_PIP_KERNEL, st);
   // a caller-owned array: the estimate the next query over it will go by, behind this query's kernels on their stream

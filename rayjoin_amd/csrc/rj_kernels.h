@@ -154,6 +154,10 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);
+// what the last launch_* wrapper of this thread launched (the kernel's name and its grid): rj_get_plan reports it
+struct LaunchNote { const char* kernel; int grid; int per_lane; };
+LaunchNote last_launch();
+LaunchNote last_strip_launch();  // (k_pip_strip lives in its own translation unit)
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a, bool stats, int max_blocks, int segs_per_lane = 1, int* segs_used = nullptr);
 hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
                                uint64_t n, unsigned long long* out2);

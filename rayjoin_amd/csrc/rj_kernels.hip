@@ -2324,6 +2324,10 @@ hipError_t warm_query_kernels(hipStream_t st) {  // (see warm_stitch_kernels)
   return hipGetLastError();
 }
 
+static thread_local LaunchNote g_note = {"", 0, 0};
+LaunchNote last_launch() { return g_note; }
+static inline void note(const char* kernel, int grid, int per_lane) { g_note.kernel = kernel; g_note.grid = grid; g_note.per_lane = per_lane; }
+
 static inline int grid_for(uint64_t work_items, int per_block, int max_blocks) {
   uint64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -2477,6 +2481,7 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
     const uint64_t by_work = ngroups / (4 * 10);  // (the small-query rule below, for groups of twice the size)
     const int floor_blocks = 512 < grid ? 512 : grid;
     if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
+    note("k_lsi2", grid, 2);
     hipLaunchKernelGGL(k_lsi2, dim3(grid), dim3(256), 0, st, a);
     if (segs_used) *segs_used = 2;
     return hipGetLastError();
@@ -2494,9 +2499,9 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
   const int floor_blocks = 512 < grid ? 512 : grid;
   if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
   if (stats)
-    hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a);
+    { note("k_lsi (instrumented)", grid, 1); hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a); }
   else
-    hipLaunchKernelGGL(k_lsi<false>, dim3(grid), dim3(256), 0, st, a);
+    { note("k_lsi", grid, 1); hipLaunchKernelGGL(k_lsi<false>, dim3(grid), dim3(256), 0, st, a); }
   return hipGetLastError();
 }
 
@@ -2572,9 +2577,9 @@ hipError_t launch_pip_walk(hipStream_t st, const PipArgs& a_in, bool stats, int 
   const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
   if (stats)
-    hipLaunchKernelGGL(k_pip_walk<true>, dim3(grid), dim3(256), lds, st, a);
+    { note("k_pip_walk (instrumented)", grid, 1); hipLaunchKernelGGL(k_pip_walk<true>, dim3(grid), dim3(256), lds, st, a); }
   else
-    hipLaunchKernelGGL(k_pip_walk<false>, dim3(grid), dim3(256), lds, st, a);
+    { note("k_pip_walk", grid, 1); hipLaunchKernelGGL(k_pip_walk<false>, dim3(grid), dim3(256), lds, st, a); }
   return hipGetLastError();
 }
 
@@ -2618,6 +2623,7 @@ hipError_t launch_pip_walk2(hipStream_t st, const PipArgs& a_in, int max_blocks,
   a.chunk_groups = a.chunk_groups ? a.chunk_groups : (P == 2 ? 3 : 2);  // (128-point groups: the same 6 x 64 positions per chunk; 256-point groups: 8 x 64)
   const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   const int grid = grid_for(nchunks, 4, res < max_blocks ? res : max_blocks);
+  note(P == 4 ? "k_pip_walk4" : "k_pip_walk2", grid, P);
   if (P == 4) {
     if (stats)
       hipLaunchKernelGGL(k_pip_walk4_stats, dim3(grid), dim3(256), lds, st, a);
@@ -2647,9 +2653,9 @@ hipError_t launch_pip(hipStream_t st, const PipArgs& a_in, bool stats, int max_b
   uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
   int grid = grid_for(nchunks, kPipWaves, res[stats] < max_blocks ? res[stats] : max_blocks);
   if (stats)
-    hipLaunchKernelGGL(k_pip<true>, dim3(grid), dim3(64 * kPipWaves), 0, st, a);
+    { note("k_pip (instrumented)", grid, 1); hipLaunchKernelGGL(k_pip<true>, dim3(grid), dim3(64 * kPipWaves), 0, st, a); }
   else
-    hipLaunchKernelGGL(k_pip<false>, dim3(grid), dim3(64 * kPipWaves), 0, st, a);
+    { note("k_pip", grid, 1); hipLaunchKernelGGL(k_pip<false>, dim3(grid), dim3(64 * kPipWaves), 0, st, a); }
   return hipGetLastError();
 }
 

@@ -104,6 +104,11 @@ __global__ __launch_bounds__(256) void k_strip_width(const QBox* __restrict__ bo
 // group; one todo mask per 64 positions, as the walk writes them).  The scans of a lane's points are independent chains
 // of dependent reads -- table, box, box, ... -- so running PTS of them side by side multiplies the reads in flight per
 // wave (the kernel has all 8 waves per SIMD already and is bound by the latency of those reads).
+// (Round 5, tried and dropped: the walk kernels' cure -- no load under a per-lane branch, the sets' loads in batches, U
+//  consecutive entries per scan step walked in registers, {slot, edge, face} looked up once at the hand-over.  Bit-exact,
+//  and 1.5-1.7x SLOWER: first pass alone 2.33 -> 3.98 / 3.59 ms at U = 1 / 4 on the lake-shaped pair, 1.96 -> 3.05 / 2.70
+//  lakes x parks.  A lane that is done must stop reading, and it can only do so behind a branch: the pass is bound by
+//  the number of lane-reads the texture path serves, not by how long a wave waits for them.)
 template <int PTS>
 __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
   __shared__ uint32_t cand_all[4][PTS * kWalkList * 64];
@@ -287,6 +292,8 @@ hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* s
   return hipGetLastError();
 }
 
+static thread_local int strip_note_grid = 0, strip_note_pts = 0;
+LaunchNote last_strip_launch() { return LaunchNote{"k_pip_strip", strip_note_grid, strip_note_pts}; }
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus) {
   // two points per lane where the query set keeps every resident wave busy with at least two 128-position groups
   // (measured, first pass alone: 2.68 -> 2.42 ms on the lake-shaped base, 4.66 -> 4.01 lakes x parks; four per lane --
@@ -296,6 +303,7 @@ hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, in
   const uint64_t ngroups = (a.n + (uint64_t) pts * 64 - 1) / ((uint64_t) pts * 64);
   int grid = blocks_for(ngroups, 4, cus * 8);
   if (grid > max_blocks) grid = max_blocks;
+  strip_note_grid = grid; strip_note_pts = pts;
   if (pts == 2) hipLaunchKernelGGL(k_pip_strip<2>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_pip_strip<1>, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();

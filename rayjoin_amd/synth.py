@@ -70,7 +70,7 @@ def _ragged(counts):
     return owner, np.arange(int(counts.sum()), dtype=np.int64) - np.repeat(starts, counts)
 
 
-def nested_refinement(base, G, k, s, k2, seed, share=0.8, node_jitter=0.25, seg_jitter=0.1):
+def nested_refinement(base, G, k, s, k2, seed, share=0.8, node_jitter=0.25, seg_jitter=0.1, detach=0.0):
     """A query map NESTED in the lattice map `base` = lattice_map(G, k, ...): every base cell is cut
     into s x s sub-cells and every base boundary is also a boundary of the refinement, the way census
     block groups nest in counties.  Sub-lattice nodes on a base line are vertices OF the base chain;
@@ -79,7 +79,11 @@ def nested_refinement(base, G, k, s, k2, seed, share=0.8, node_jitter=0.25, seg_
     lsi.h:42-100, and PIP points that lie exactly on base vertices, pip.h:44-93), the others run
     between the same two shared vertices with their own jitter (a differently generalised copy of the
     boundary: it crosses the base chain every few segments).  Interior sub-chains have k2 segments and
-    end ON base vertices where they meet a base line (T-junctions at shared vertices)."""
+    end ON base vertices where they meet a base line (T-junctions at shared vertices).
+    `detach`: of the sub-chains along base lines that do not reuse the base vertices, this fraction runs BESIDE the base
+    chain (its interior pushed to one side by 0.6-0.9 of a segment's length) and meets it only at its two end vertices --
+    a boundary drawn from another source; the rest weave across it.  With `share` it sets the pair's intersection
+    density (CrossingZipcode: the published County x Zipcode density)."""
     rng = np.random.default_rng(seed)
     G2 = s * G
     bp = base.points.reshape(-1, k + 1, 2)                      # base chain c = bp[c]
@@ -131,6 +135,11 @@ def nested_refinement(base, G, k, s, k2, seed, share=0.8, node_jitter=0.25, seg_
     perp = np.stack([-d[:, 1], d[:, 0]], 1) / ln[:, None]
     jit = rng.uniform(-seg_jitter, seg_jitter, len(owner)) * (ln / nseg)[owner]
     jit[(t == 0) | (t == nseg[owner])] = 0.0
+    if detach > 0:
+        away = on_base & ~shared & (rng.random(on_base.shape) < detach)
+        side = np.where(rng.random(on_base.shape) < 0.5, -1.0, 1.0)
+        aw = away[owner] & (t > 0) & (t < nseg[owner])
+        jit[aw] = (side[owner] * (0.6 + 0.3 * rng.random(len(owner))) * (ln / nseg)[owner])[aw]
     pts = (1 - f) * P0[owner] + f * P1[owner] + jit[:, None] * perp[owner]
     ends0, ends1 = t == 0, t == nseg[owner]
     pts[ends0] = P0[owner[ends0]]                                 # shared vertices bit for bit
@@ -303,7 +312,19 @@ def _nested_blockgroup(scale):
     return nested_refinement(lattice_map(G, k, seed, bbox), G, k, 6, 33, seed=7)
 
 
+def _crossing_zipcode(scale):
+    """A Zipcode-sized query map (23.7 M segments) whose boundaries CROSS the USCounty stand-in's at the density the
+    reference's logs show for the real County x Zipcode pair (833 470 intersections / 23.76 M query segments = 3.5 %,
+    BASELINE.md; the independent lattices give 0.3 %, the nested refinement 7.5 %): a 3 x 3 refinement of the county cells
+    whose boundaries along county lines are mostly drawn beside the county's own (another source's generalisation), one in
+    five weaves across it, one in twenty reuses its vertices."""
+    G, k, seed, bbox = STANDINS["USCounty"]
+    G = max(2, int(round(G * scale)))
+    return nested_refinement(lattice_map(G, k, seed, bbox), G, k, 3, 130, seed=9, share=0.05, detach=0.8)
+
+
 EXTRA = {
+    "CrossingZipcode": _crossing_zipcode,
     "NestedBlockGroup": _nested_blockgroup,                       # refines the USCounty stand-in (same seed): 28.1 M segments
     "Gaussian5M": lambda scale: gaussian_polygons(max(16, int(5_000_000 * scale * scale)), 1),
     "Gaussian1M": lambda scale: gaussian_polygons(max(16, int(1_000_000 * scale * scale)), 2),
