@@ -1971,6 +1971,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
     }
     wave_min_max_min(gx0, gx1, gy0);
     int32_t gbest = 0x7FFFFFFF;  // wave max of both sets' qbest
+    bool gbest_stale = false;    // ... some lane's bound has dropped since it was last reduced (wave-uniform)
 
     auto refine_if_many = [&](const QBox& b, uint64_t um) -> uint64_t {
       if (__popcll(um) <= kPipRefineAbove) return um;
@@ -2028,6 +2029,13 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         asm volatile("" : "+v"(lane_here));
         const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane_here];
         const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane_here];
+        if (gbest_stale) {  // (while the boxes are on their way)
+          gbest_stale = false;
+          int32_t lane_best = qbest[0] > qbest[1] ? qbest[0] : qbest[1];
+#pragma unroll
+          for (int p = 2; p < P; p++) lane_best = lane_best > qbest[p] ? lane_best : qbest[p];
+          gbest = wave_max(lane_best);
+        }
         uint64_t m = refine_if_many(b, __ballot(b.x0 <= gx1 && gx0 <= b.x1 && b.y1 >= gy0 - 1 && b.y0 <= gbest));
         if (sp + __popcll(m) > stack_cap) { ovf = true; break; }  // (the group leaves the walk: see kWalkStack)
         if ((m >> lane) & 1)
@@ -2052,7 +2060,10 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         for (int p = 0; p < P; p++) {
           if (!__ballot(want[p])) continue;  // none of this set's points is under this block
           if (STATS) { st_setvisits++; st_want += (unsigned long long) __popcll(__ballot(want[p])); }
-          const uint32_t bk = want[p] ? ((uint32_t) qx[p] - sx0s) >> sh : 0u;
+          // (a lane that does not want the block computes on whatever its x gives: every cross-lane read masks its
+          //  index, such a lane's j is set to -1 below, and no box of the block can pass its test -- its x lies outside
+          //  the block or its bound below the block: two selects less per visit)
+          const uint32_t bk = ((uint32_t) qx[p] - sx0s) >> sh;
           const uint32_t bsh = (bk & 3u) * 8u;
           const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
           const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
@@ -2064,7 +2075,6 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
             jlo += low_x1 < qx[p] ? 1 : 0;
           }
           j = want[p] ? j : -1;
-          jlo = want[p] ? jlo : 0;
           const int32_t qbest_before = qbest[p];
           auto scan_step = [&]() {
                   if (STATS) st_steps++;
@@ -2094,7 +2104,11 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
           }
           changed = changed || qbest[p] != qbest_before;
         }
-        if (__ballot(changed)) {
+        // (the group's bound is what a node expansion filters its pushes by and what a sweep drops entries by: with at
+        //  most one entry left neither may ever happen again -- the reduction waits until an expansion asks for it)
+        if (__ballot(changed)) gbest_stale = true;
+        if (gbest_stale && sp > 1) {
+          gbest_stale = false;
           const int32_t gbest_before = gbest;
           int32_t lane_best = qbest[0] > qbest[1] ? qbest[0] : qbest[1];
 #pragma unroll

@@ -30,7 +30,7 @@ def short(name):
     return name.split("(")[0][:40]
 
 
-KERNELS = ("k_lsi", "k_lsi2", "k_pip_walk", "k_pip_walk2", "k_pip_exact", "k_pip", "k_lsi_points", "k_lsi_points_gcd")
+KERNELS = ("k_lsi", "k_lsi2", "k_pip_walk", "k_pip_walk2", "k_pip_walk4", "k_pip_strip", "k_pip_exact", "k_pip", "k_lsi_points", "k_lsi_points_gcd")
 
 
 def full_grid(vals):
@@ -51,17 +51,8 @@ def collect(d):
     return acc
 
 
-def main():
-    tag, fetch_dir, write_dir = sys.argv[1:4]
-    if len(sys.argv) > 4:
-        with open(os.path.join(ROOT, "profiles", "%s_sq_counters.csv" % tag), "w") as f:
-            f.write("counter,kernel,dispatches,avg_value\n")
-            for d in sys.argv[4:]:
-                for counter, per_kernel in sorted(collect(d).items()):
-                    for kern in KERNELS:
-                        v = full_grid(per_kernel.get(kern))
-                        if v:
-                            f.write("%s,%s,%d,%.0f\n" % (counter, kern, len(v), sum(v) / len(v)))
+def summarise(fetch_dir, write_dir, sq_dirs):
+    """-> (rows of the FETCH/WRITE table, traffic per kernel, SQ counters per kernel) of one set of counter passes"""
     acc = collect(fetch_dir)
     for k, v in collect(write_dir).items():
         acc[k].update(v)
@@ -70,29 +61,61 @@ def main():
         for kern, vals in sorted(acc.get(counter, {}).items()):
             vals = full_grid(vals) if kern in KERNELS else vals
             rows.append((counter, kern, len(vals), sum(vals) / len(vals)))
-    out = os.path.join(ROOT, "profiles", "%s_pmc_summary.csv" % tag)
-    with open(out, "w") as f:
-        f.write("counter,kernel,dispatches,avg_value_KB\n")
-        for r in rows:
-            f.write("%s,%s,%d,%.1f\n" % r)
     avg = {(c, k): v for c, k, _, v in rows}
     traffic = {}
     for kern in KERNELS:
         if ("FETCH_SIZE", kern) in avg and ("WRITE_SIZE", kern) in avg:
             traffic[kern] = int((2 * avg[("FETCH_SIZE", kern)] + avg[("WRITE_SIZE", kern)]) * 1024)
     # instruction-issue evidence for the bench line's "limiter" (SQ passes, optional)
-    sq = {}
-    for d in sys.argv[4:]:
-        for counter, per_kernel in collect(d).items():
+    sq, sq_rows = {}, []
+    for d in sq_dirs:
+        for counter, per_kernel in sorted(collect(d).items()):
             for kern in KERNELS:
                 v = full_grid(per_kernel.get(kern))
                 if v:
                     sq.setdefault(kern, {})[counter] = sum(v) / len(v)
+                    sq_rows.append((counter, kern, len(v), sum(v) / len(v)))
+    return rows, traffic, sq, sq_rows
+
+
+def main():
+    """pmc_summary.py <tag> <fetch_dir> <write_dir> [<sq_dir> ...] [--section <name> <fetch_dir> <write_dir> <sq_dir> <sq_dir>] ...
+    The first set = the headline pair, every kernel alone on its full grid (bench.py --serial-kernels); a --section is
+    another regime or pair (tools/regime_probe.py): "shared" = the headline's kernels on the grids of the shared schedule,
+    "<base>_<query>" = another pair.  All of it goes to profiles/traffic.json; bench.py quotes a section by its name."""
+    argv = sys.argv[1:]
+    sections = []
+    while "--section" in argv:
+        i = argv.index("--section")
+        sections.append(argv[i + 1:i + 6])
+        argv = argv[:i] + argv[i + 6:]
+    tag, fetch_dir, write_dir = argv[:3]
+    rows, traffic, sq, sq_rows = summarise(fetch_dir, write_dir, argv[3:])
+    if sq_rows:
+        with open(os.path.join(ROOT, "profiles", "%s_sq_counters.csv" % tag), "w") as f:
+            f.write("counter,kernel,dispatches,avg_value\n")
+            for r in sq_rows:
+                f.write("%s,%s,%d,%.0f\n" % r)
+    out = os.path.join(ROOT, "profiles", "%s_pmc_summary.csv" % tag)
+    with open(out, "w") as f:
+        f.write("counter,kernel,dispatches,avg_value_KB\n")
+        for r in rows:
+            f.write("%s,%s,%d,%.1f\n" % r)
     sys.path.insert(0, ROOT)
     from rayjoin_amd._capi import kernel_source_hash
-    doc = {"tag": tag, "kernel_source_hash": kernel_source_hash(), "traffic": traffic, "sq": sq}
+    doc = {"tag": tag, "kernel_source_hash": kernel_source_hash(), "traffic": traffic, "sq": sq, "sections": {}}
+    if sections:
+        with open(os.path.join(ROOT, "profiles", "%s_pmc_sections.csv" % tag), "w") as f:
+            f.write("section,counter,kernel,dispatches,avg_value\n")
+            for name, fd, wd, s1, s2 in sections:
+                r2, t2, q2, sr2 = summarise(fd, wd, [s1, s2])
+                doc["sections"][name] = {"traffic": t2, "sq": q2}
+                for r in r2:
+                    f.write("%s,%s_KB,%s,%d,%.1f\n" % ((name, r[0]) + r[1:]))
+                for r in sr2:
+                    f.write("%s,%s,%s,%d,%.0f\n" % ((name,) + r))
     json.dump(doc, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-    print(out, doc)
+    print(out, json.dumps(doc)[:600])
 
 
 if __name__ == "__main__":

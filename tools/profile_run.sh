@@ -23,4 +23,19 @@ cd $R
 python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --regimes > gpurun_out/${TAG}_kernel_regimes.csv
 python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --steps 3 --skip 4 > gpurun_out/${TAG}_step_trace.txt
 timeout -k 10 500 python3 bench.py --check --steps 20 --warmup 5 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench.json
-tail -c 300 gpurun_out/${TAG}_bench.json
+tail -c 300 gpurun_out/${TAG}_bench.json || true
+# Round 5: sections of counter passes beside the headline's full grids (tools/regime_probe.py: the profiler serialises
+# kernels, so a regime is profiled kernel by kernel on that regime's grids).  "shared" = the headline's kernels on the
+# grids of the shared schedule (k_lsi2 on 512 blocks, k_pip_walk2 on 1 536); the ring-shaped pairs on their full grids.
+cd /tmp
+section() {  # name, regime_probe arguments ...
+  local NAME=$1; shift
+  for P in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq1:SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "sq2:SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE"; do
+    timeout -k 10 300 rocprofv3 --pmc ${P#*:} --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_${NAME}_${P%%:*} -o g -- python3 $R/tools/regime_probe.py "$@" > $R/gpurun_out/${TAG}_${NAME}_${P%%:*}.log 2>&1
+  done
+  echo "section $NAME done"
+}
+if [[ " ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike} " == *" shared "* ]]; then section shared --lsi-blocks 512 --pip-blocks 1536; fi
+if [[ " ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike} " == *" WaterBodiesLike_BlockGroup "* ]]; then section WaterBodiesLike_BlockGroup --base WaterBodiesLike --query BlockGroup; fi
+if [[ " ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike} " == *" LakesLike_ParksLike "* ]]; then section LakesLike_ParksLike --base LakesLike --query ParksLike; fi
+cd $R
