@@ -814,7 +814,8 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     }
     const QBox root_box = T.lvl[T.top][lane];  // (requested beside the segments: one round trip, not two)
     {
-      const Seg s = A.qseg[q];
+      Seg s = Seg{0, 0, 0, 0};
+      if (near) s = A.qseg[q];  // (a masked load: a lane the pre-filter cleared reads nothing)
       if (near) {
         qx0 = quant(s.x1 < s.x2 ? s.x1 : s.x2);
         qx1 = quant(s.x1 < s.x2 ? s.x2 : s.x1);
@@ -987,18 +988,26 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     if (occ_usable) {
 #pragma unroll
       for (int p = 0; p < 2; p++) code[p] = __builtin_nontemporal_load(A.qcode + q[p]);
+      asm volatile("" : "+v"(code[0]), "+v"(code[1]));  // (both codes requested before either is used: the scheduler would otherwise put set 1's behind set 0's windows)
       OccWindows win[2];
 #pragma unroll
       for (int p = 0; p < 2; p++) win[p] = occ_fetch_code(T.occ, code[p]);
+      asm volatile("" : "+v"(win[0].a), "+v"(win[0].b), "+v"(win[1].a), "+v"(win[1].b));
 #pragma unroll
       for (int p = 0; p < 2; p++) near[p] = near[p] && occ_verdict_code(win[p], code[p]);
     }
     if (!__ballot(near[0] || near[1])) continue;  // both halves of the group are clear of the base map
     const QBox root_box = T.lvl[T.top][lane];
     {
+      // (only the lanes the pre-filter let through read their segment -- two thirds of a passing group's lanes are clear of
+      //  the base map too, and unmasked these loads doubled the kernel's traffic, 0.46 -> 0.93 GB -- but both sets' loads
+      //  stand before the first use of either: one round trip)
       Seg sg[2];
 #pragma unroll
-      for (int p = 0; p < 2; p++) sg[p] = A.qseg[q[p]];
+      for (int p = 0; p < 2; p++) {
+        sg[p] = Seg{0, 0, 0, 0};
+        if (near[p]) sg[p] = A.qseg[q[p]];
+      }
 #pragma unroll
       for (int p = 0; p < 2; p++) {
         const Seg& s = sg[p];

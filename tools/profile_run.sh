@@ -14,6 +14,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 # (the driver's flags; the four schedule trials are warm-up steps, every timed step runs the settled schedule;
 #  tools/trace_tables.py splits the per-kernel averages by grid size = by regime)
+if [[ "${PASSES:-headline}" == "headline" ]]; then
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_kt -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --steps 20 --warmup 5 > $R/gpurun_out/${TAG}_kt.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_fetch -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --serial-kernels > $R/gpurun_out/${TAG}_fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_write -o g -- python3 $R/bench.py --no-cpu-baseline --no-secondary --serial-kernels > $R/gpurun_out/${TAG}_write.log 2>&1
@@ -24,6 +25,7 @@ python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --regimes 
 python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --steps 3 --skip 4 > gpurun_out/${TAG}_step_trace.txt
 timeout -k 10 500 python3 bench.py --check --steps 20 --warmup 5 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench.json
 tail -c 300 gpurun_out/${TAG}_bench.json || true
+fi
 # Round 5: sections of counter passes beside the headline's full grids (tools/regime_probe.py: the profiler serialises
 # kernels, so a regime is profiled kernel by kernel on that regime's grids).  "shared" = the headline's kernels on the
 # grids of the shared schedule (k_lsi2 on 512 blocks, k_pip_walk2 on 1 536); the ring-shaped pairs on their full grids.
