@@ -793,7 +793,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
       {"pip_share_blocks", &h->pip_share_set, 0, 1 << 20},
       {"stack_cap", &h->debug_stack_cap, 1, 1 << 30},     // instrumented kernels: fewer traversal-stack entries (fault path)
       {"walk_stack", &h->debug_walk_stack, 0, 1 << 30},   // k_pip_walk*: fewer stack entries (groups that need more leave the walk)
-      {"strip_shift", &h->debug_strip_shift, 0, 20},      // the column index on strips of 2^this quanta (0: chosen by the map; 14..20)
+      {"strip_shift", &h->debug_strip_shift, 0, 20},      // the column index on strips of 2^this quanta (0: chosen by the map; 15..20)
       {"run_cap", &h->debug_run_cap, 0, 64},              // edges per polyline run of the next first build of a map (0: 64)
       {"pack_solo", &h->debug_pack_solo, 0, 64},          // a run longer than this never shares its leaf (0: 48)
       {"pack_spread", &h->debug_pack_spread, 0, 1000000}, // a shared leaf may be this many times as large as its runs (0: 8)
@@ -802,7 +802,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
     if (!strcmp(name, k.name)) {
       if (value < k.lo || value > k.hi) return fail(h, RJ_E_INVALID, "%s: %lld..%lld", name, (long long) k.lo, (long long) k.hi);
       if (!strcmp(name, "run_cap") && value == 1) return fail(h, RJ_E_INVALID, "run_cap: 0 or 2..64");
-      if (!strcmp(name, "strip_shift") && value != 0 && value < 14) return fail(h, RJ_E_INVALID, "strip_shift: 0 or 14..20");
+      if (!strcmp(name, "strip_shift") && value != 0 && value < 15) return fail(h, RJ_E_INVALID, "strip_shift: 0 or 15..20 (the sort key holds 16 bits of strip)");
       *k.var = (int) value;
       return RJ_OK;
     }
@@ -1027,8 +1027,9 @@ static int build_strips(rj_handle h, BvhState& b) {
     tb = scan_bytes;
     RJ_HIP(h, launch_strip_count(h->stream, b.box0, b.seid, b.n0p, shift, cnt, offs, temp, tb, flag));
   }
-  uint64_t* key_tmp = (uint64_t*) (h->strip_scratch + 2 * cnt_bytes + 256);
-  uint64_t* key = (uint64_t*) ((char*) key_tmp + up(8 * (size_t) total));
+  // (32-bit keys since round 5 -- strip above the band of y0, rj_strip.hip -- in the room the 64-bit ones had)
+  uint32_t* key_tmp = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes + 256);
+  uint32_t* key = (uint32_t*) ((char*) key_tmp + up(8 * (size_t) total));
   uint32_t* slot_tmp = (uint32_t*) ((char*) key + up(8 * (size_t) total));
   uint32_t* slot_sorted = (uint32_t*) ((char*) slot_tmp + up(4 * (size_t) total));
   uint32_t* tall_tmp = (uint32_t*) ((char*) slot_sorted + up(4 * (size_t) total));

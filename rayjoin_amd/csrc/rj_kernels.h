@@ -130,7 +130,7 @@ hipError_t launch_strip_width(hipStream_t st, const QBox* box0, const uint32_t* 
 hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, int shift, uint32_t* cnt, uint32_t* offs,
                               void* temp, size_t& temp_bytes, uint32_t* flag);
 hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* seid, const int32_t* sface, const uint32_t* cnt,
-                             const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint64_t* key, uint32_t* eslot, uint64_t* key_tmp,
+                             const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint32_t* key, uint32_t* eslot, uint32_t* key_tmp,
                              uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, void* temp,
                              size_t& temp_bytes);
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus);

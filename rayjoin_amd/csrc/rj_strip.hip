@@ -43,8 +43,14 @@ __global__ __launch_bounds__(256) void k_strip_count(const QBox* __restrict__ bo
     cnt[i] = c;
   }
 }
+// The sort key of an entry, 32 bits: its strip above the BAND of its y0 (2^15 quanta).  The column's entries ascend by
+// band, not by y0 itself: the scan stops at the first band above the point's bound and tests every entry of the bands
+// before -- a handful more than the exact order would -- while the key is half as wide and two radix passes shorter
+// (round 4: 64-bit keys of 47 bits, six passes -- most of the index's 5-11 ms).
+constexpr int kStripBandShift = 15, kStripBandBits = 31 - kStripBandShift;
+__device__ __forceinline__ uint32_t strip_key(uint32_t strip, int32_t y0) { return (strip << kStripBandBits) | ((uint32_t) y0 >> kStripBandShift); }
 __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box0, const uint32_t* __restrict__ cnt,
-                                                    const uint32_t* __restrict__ offs, uint64_t n0p, int shift, uint64_t* __restrict__ key,
+                                                    const uint32_t* __restrict__ offs, uint64_t n0p, int shift, uint32_t* __restrict__ key,
                                                     uint32_t* __restrict__ slot, uint32_t* __restrict__ tall) {
   RJ_GRID_STRIDE(i, n0p) {
     const uint32_t c = cnt[i];
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box
     const uint32_t s0 = (uint32_t) (b.x0 >> shift), h = (uint32_t) (b.y1 - b.y0);
     const uint32_t o = offs[i];
     for (uint32_t k = 0; k < c; k++) {
-      key[o + k] = ((uint64_t) (s0 + k) << 32) | (uint32_t) b.y0;
+      key[o + k] = strip_key(s0 + k, b.y0);
       slot[o + k] = (uint32_t) i;
       if (__hip_atomic_load(&tall[s0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < h) atomicMax(&tall[s0 + k], h);
     }
@@ -64,10 +70,10 @@ __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box
 // bucket with the entry count); a suffix minimum over the table then gives every empty bucket the first entry behind
 // it.  (Filling the gaps from the entries themselves left one thread writing millions of buckets where the map is a
 // small cluster in a large domain: +7 ms on the gaussian polygons.)
-__device__ __forceinline__ uint32_t strip_bucket(uint64_t key) {
-  return ((uint32_t) (key >> 32) << kStripYBits) | ((uint32_t) key >> kStripYShift);
+__device__ __forceinline__ uint32_t strip_bucket(uint32_t key) {
+  return ((key >> kStripBandBits) << kStripYBits) | ((key & ((1u << kStripBandBits) - 1u)) >> (kStripYShift - kStripBandShift));
 }
-__global__ __launch_bounds__(256) void k_strip_finish(const uint64_t* __restrict__ key, const uint32_t* __restrict__ slot, uint64_t n,
+__global__ __launch_bounds__(256) void k_strip_finish(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot, uint64_t n,
                                                       const QBox* __restrict__ box0, const uint32_t* __restrict__ seid,
                                                       const int32_t* __restrict__ sface, QBox* __restrict__ ebox,
                                                       uint4* __restrict__ einfo, uint32_t* __restrict__ ytab, uint32_t strips) {
@@ -174,8 +180,9 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
 #pragma unroll
       for (int p = 0; p < PTS; p++) {
         if (j[p] >= jend[p]) continue;
-        if (b[p].y0 > qbest[p]) { j[p] = jend[p]; continue; }  // everything further starts above the bound
-        if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p])) >= 0) {
+        // (the entries ascend by BAND of y0, 2^15 quanta: inside a band their order is the build's)
+        if ((b[p].y0 >> kStripBandShift) > (qbest[p] >> kStripBandShift)) { j[p] = jend[p]; continue; }  // everything further starts above the bound
+        if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p]) | (qbest[p] - b[p].y0)) >= 0) {
           // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
           // ends below the start of the one certain hit held so far replaces it
           const uint4 inf = S.einfo[j[p]];  // {slot, edge id, face id}: one 16-byte read
@@ -259,14 +266,14 @@ hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* 
 // pass 2: the entries, sorted by (strip, y0), with their boxes, their {slot, edge id, face id} and the height-bucket
 // table; key / eslot / key_tmp / slot_tmp: temporaries of `entries` elements; tall[strips] (temporary) zeroed here
 hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* seid, const int32_t* sface, const uint32_t* cnt,
-                             const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint64_t* key, uint32_t* eslot, uint64_t* key_tmp,
+                             const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint32_t* key, uint32_t* eslot, uint32_t* key_tmp,
                              uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, void* temp,
                              size_t& temp_bytes) {
-  const unsigned bits = 32 + (31 - shift);
+  const unsigned bits = (unsigned) kStripBandBits + (31 - shift);  // (<= 32: strips of 2^15 quanta or wider)
   const uint32_t strips = strip_count(shift);
   if (!temp) {
     size_t a = 0, b = 0;
-    hipError_t q = rocprim::radix_sort_pairs(nullptr, a, (const uint64_t*) nullptr, (uint64_t*) nullptr, (const uint32_t*) nullptr,
+    hipError_t q = rocprim::radix_sort_pairs(nullptr, a, (const uint32_t*) nullptr, (uint32_t*) nullptr, (const uint32_t*) nullptr,
                                              (uint32_t*) nullptr, (size_t) entries, 0, bits, st);
     if (q != hipSuccess) return q;
     uint32_t* z = nullptr;
