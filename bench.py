@@ -478,12 +478,21 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         traffic, sq, prof_note = {}, {}, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         is_headline = headline and world == 1 and args.scale == 1.0 and not args.emulate_shard and (base_name, query_name) == ("USCounty", "BlockGroup")
-        if os.path.exists(tp) and is_headline:
+        shared_sq = {}
+        plain = world == 1 and args.scale == 1.0 and not args.emulate_shard
+        if os.path.exists(tp) and plain:
             doc = json.load(open(tp))
-            if doc.get("kernel_source_hash") == _capi.kernel_source_hash():
+            sec = doc.get("sections", {}).get("%s_%s" % (base_name, query_name))
+            if doc.get("kernel_source_hash") != _capi.kernel_source_hash():
+                if is_headline or sec:
+                    prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
+            elif is_headline:
                 traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_* (counter passes: each kernel alone on its full grid)" % doc.get("tag")
-            else:
-                prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
+                # (the same kernels on the grids of the shared schedule -- k_lsi2 on 512 blocks, the walk on 1 536 -- profiled one
+                #  after the other: rocprofv3 serialises the kernels of a counter pass, tools/regime_probe.py)
+                shared_sq = doc.get("sections", {}).get("shared", {}).get("sq", {})
+            elif sec:  # (another pair with a section of its own: the ring-shaped ones)
+                traffic, sq, prof_note = sec.get("traffic", {}), sec.get("sq", {}), "profiles/%s_pmc_sections.csv, section %s_%s (each kernel alone on its full grid)" % (doc.get("tag"), base_name, query_name)
         # (a base map of isolated rings has a column index: the first pass reads the point's strip instead of walking the tree)
         walk_name = "k_pip_strip" if state.get("columns") else ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk")
         pip_kernel = walk_name if state["two_pass"] else "k_pip"
@@ -538,10 +547,22 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                                                  "unit": "G wave-instructions/s", "frac": round(ach / peak, 4),
                                                  "measured_on": "the kernel alone on its full grid (PMC pass)"}
                     if kern.startswith("k_pip_walk") and is_headline:
+                        # (per 128-position group of k_pip_walk2, instrumented: profiles/r05_walk_stats.txt -- 10.4 pops (1.3 stale), 3.7 node
+                        #  expansions, 5.4 leaf blocks = 7.5 (leaf, set) visits with 20.5 of 64 lanes wanting, 8.2 scan steps, 7.2 candidate
+                        #  bodies, 1.1 sweeps; priced with the instruction counts of the kernel's ISA)
                         r["instruction_roofline"]["floor_valu_per_query"] = 3.8
-                        r["instruction_roofline"]["floor_note"] = ("3.6 node expansions x 8 + 3.7 leaf visits x 20 + 4.0 scan steps x 12 + 60 per 64-point group "
-                                                                   "(counts: profiles/r04_leaf_order.txt); the kernel issues %.1f per point -- the rest is "
-                                                                   "19 pops (11.5 stale), stack sweeps and the scheduler" % r["valu_per_query"])
+                        r["instruction_roofline"]["floor_note"] = ("per 128-position group: 7.5 (leaf, set) visits x (22 lookup + 9 test) + 7.2 candidate bodies x 17 = 2.8 per point "
+                                                                   "is the work itself at a third of the lanes; 10.4 pops x 9, 3.7 expansions x 25, the group's bound, "
+                                                                   "sweeps, load / hand-over / scheduler are the other %.1f (profiles/r05_walk_stats.txt)" % (r["valu_per_query"] - 2.8))
+            cs = shared_sq.get(kern, {})
+            if cs.get("SQ_INSTS_VALU") and cs.get("GRBM_GUI_ACTIVE"):
+                units = n_p_loc if name == "pip" else n_s_loc
+                avail = cs["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
+                r["on_its_share_of_the_chip"] = {
+                    "note": "the kernel ALONE on the grid it has in the shared schedule (counter passes serialise kernels: the other side's instructions are not in these numbers)",
+                    "valu_per_query": round(cs["SQ_INSTS_VALU"] / units, 2), "salu_per_query": round(cs.get("SQ_INSTS_SALU", 0) / units, 2),
+                    "valu_busy_frac": round(cs.get("SQ_ACTIVE_INST_VALU", 0) / avail, 3),
+                    "wait_frac_of_wave_cycles": round(cs.get("SQ_WAIT_ANY", 0) / cs["SQ_WAVE_CYCLES"], 3) if cs.get("SQ_WAVE_CYCLES") else None}
             roof[name] = r
         roof["pip"]["query_ms"] = round(pip_k, 4)  # all PIP kernels of a step, first launch to last end
         roof["pip"]["frac_query"] = round(b_pip / (pip_k * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)

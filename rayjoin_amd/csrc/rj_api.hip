@@ -1613,7 +1613,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   const uint32_t* order = nullptr;
   // (a base map with a column index answers every point on its own -- nothing is shared between the points of a wave,
   //  so a scattered query set needs no re-ordering there)
-  const bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && !h->stats_on;
+  const bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && (!h->stats_on || h->pip_walk == 2);
   if (by_columns && h->query_order != 2) { h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr; }
   else if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
   // "pip_concurrent": the kernel goes to the handle's second stream and runs BESIDE the LSI kernel
@@ -1739,7 +1739,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
                      n >= (uint64_t) wp * 256 * 4 * h->cus * pip_walk2_blocks_per_cu(w.bvh.top, wp);  // (four groups per resident wave)
     tic(h, RJ_T_PIP_WALK, st);
     // a base map with a column index (isolated rings): the first pass reads the point's strip instead of walking the tree
-    const bool columns = w.bvh.strips.ytab != nullptr && !h->stats_on;
+    const bool columns = w.bvh.strips.ytab != nullptr;  // (instrumented too: k_pip_strip counts its scans)
     h->last_columns = columns ? 1 : 0;
     if (columns) {
       w.group_lanes = 64;  // (one todo mask per 64 positions)

@@ -115,7 +115,16 @@ __global__ __launch_bounds__(256) void k_strip_width(const QBox* __restrict__ bo
 //  and 1.5-1.7x SLOWER: first pass alone 2.33 -> 3.98 / 3.59 ms at U = 1 / 4 on the lake-shaped pair, 1.96 -> 3.05 / 2.70
 //  lakes x parks.  A lane that is done must stop reading, and it can only do so behind a branch: the pass is bound by
 //  the number of lane-reads the texture path serves, not by how long a wave waits for them.)
-template <int PTS>
+// (entries a point reads on its own before the wave takes its scan over.  First pass, ms, at 8 / 12 / 16 / 24 / 32 / 48 / 64 /
+//  never: lake-shaped base x lattice vertices 2.70 / 2.32 / 2.14 / 1.92 / 1.80 / 1.86 / 1.95 / 2.13; lakes x parks 2.40 / 1.87 /
+//  1.68 / 1.61 / 1.62 / 1.70 / 1.77 / 1.94; gaussian polygons 1.27 / 0.93 / 0.75 / 0.62 / 0.59 / 0.58 / 0.59 / 0.58: a
+//  cooperative trip costs about three solo ones, so it pays for the 3 % of the points that need more than 32 entries --
+//  which nearly every wave has -- and not for the 10 % beyond 16)
+#ifndef RJ_STRIP_SOLO
+#define RJ_STRIP_SOLO 32
+#endif
+constexpr int kStripSolo = RJ_STRIP_SOLO;
+template <int PTS, bool STATS = false>
 __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
   __shared__ uint32_t cand_all[4][PTS * kWalkList * 64];
   const int lane = lane_id();
@@ -171,15 +180,26 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
         jend[p] = te.y;
       }
     }
-    for (;;) {
+    uint32_t st_coop = 0;  // STATS: trips of the cooperative phase
+    uint32_t st_len[PTS], st_below[PTS], st_iter = 0;  // STATS: entries this lane's point read, those that end below it, the wave's trips
+#pragma unroll
+    for (int p = 0; p < PTS; p++) st_len[p] = st_below[p] = 0;
+    // Every point scans its column on its own for at most kStripSolo entries (a wave's trip = one read per point set);
+    // whoever is not done by then -- a tenth of the points of the lake-shaped pair, but nearly every wave has some, and a
+    // wave went on until its slowest lane was done: ~60 trips for points that need 7.5 entries on average -- is finished
+    // by the whole wave, 64 consecutive entries per trip (below).
+    const int solo = A.walk_stack > 0 ? A.walk_stack : kStripSolo;  // ("walk_stack", a debug knob: experiments with the hand-over point)
+    for (int trip = 0; trip < solo; trip++) {
       bool more = false;
       QBox b[PTS];
+      if (STATS) st_iter++;
 #pragma unroll
       for (int p = 0; p < PTS; p++)   // (the reads of all points first: they are what the lane waits for)
         if (j[p] < jend[p]) b[p] = S.ebox[j[p]];
 #pragma unroll
       for (int p = 0; p < PTS; p++) {
         if (j[p] >= jend[p]) continue;
+        if (STATS) { st_len[p]++; st_below[p] += b[p].y1 < qym1[p] ? 1u : 0u; }
         // (the entries ascend by BAND of y0, 2^15 quanta: inside a band their order is the build's)
         if ((b[p].y0 >> kStripBandShift) > (qbest[p] >> kStripBandShift)) { j[p] = jend[p]; continue; }  // everything further starts above the bound
         if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p]) | (qbest[p] - b[p].y0)) >= 0) {
@@ -202,7 +222,88 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
         j[p]++;
         more = more || j[p] < jend[p];
       }
-      if (!more) break;
+      if (!__ballot(more)) break;
+    }
+    // The long scans, one point at a time, by the whole wave: its state goes to scalar registers, lane k reads entry j + k
+    // (one coalesced kilobyte), the tests run on all 64 at once.  The bookkeeping is the solo scan's in set form: the
+    // certain hits of the batch lower the bound first, a candidate is an entry over the point's x that starts at or below
+    // it, the one certain hit held so far is dropped if it now starts above; exactly one candidate in all, a certain one,
+    // settles the point (its edge and face come from that lane), more go to the list, too many to the rest list.
+#pragma unroll
+    for (int p = 0; p < PTS; p++) {
+      uint64_t todo_m = __ballot(j[p] < jend[p]);
+      while (todo_m) {
+        const int o = __builtin_ctzll(todo_m);
+        todo_m &= todo_m - 1;
+        const int32_t oqx = bcast(qx[p], o), oqy = bcast(qy[p], o), oqym1 = bcast(qym1[p], o);
+        int32_t oqbest = bcast(qbest[p], o), osure = bcast(sure_y0[p], o);
+        uint32_t oj = (uint32_t) bcast((int32_t) j[p], o);
+        const uint32_t ojend = (uint32_t) bcast((int32_t) jend[p], o);
+        const uint32_t obase = (uint32_t) o + (uint32_t) p * (kWalkList * 64);
+        uint32_t oat = (uint32_t) bcast((int32_t) cand_at[p], o);
+        uint32_t oeid = (uint32_t) bcast((int32_t) sure_eid[p], o), oface = (uint32_t) bcast((int32_t) sure_face[p], o);
+        bool stop = false;
+        while (!stop && oj < ojend) {
+          if (STATS) st_coop++;
+          const uint32_t idx = oj + (uint32_t) lane;
+          const bool in = idx < ojend;
+          QBox e = {0, 0, 0, 0};
+          if (in) e = S.ebox[idx];
+          // (ascending by band: from the first entry of a band above the bound on, nothing counts)
+          const uint64_t bm = __ballot(in && (e.y0 >> kStripBandShift) > (oqbest >> kStripBandShift));
+          stop = bm != 0;
+          const bool live = in && (bm == 0 || lane < __builtin_ctzll(bm));
+          const bool pass = live && ((oqx - e.x0) | (e.x1 - oqx) | (e.y1 - oqym1)) >= 0;
+          const bool certain = pass && e.x0 < oqx && oqx < e.x1 && e.y0 > oqy;
+          const int32_t nb = wave_min(certain ? e.y1 + 1 : 0x7FFFFFFF);
+          oqbest = nb < oqbest ? nb : oqbest;
+          const bool is_cand = pass && e.y0 <= oqbest;
+          const uint64_t cm = __ballot(is_cand);
+          if (cm) {
+            if (osure != INT32_MIN && osure > oqbest) { oat = obase; osure = INT32_MIN; }  // (the held hit lies above the new bound)
+            const uint32_t nc = (uint32_t) __popcll(cm), fill = (oat - obase) >> 6;
+            if (fill + nc > (uint32_t) kWalkList) {  // the list would overflow: the rest list takes the point
+              oat = obase + (uint32_t) (kWalkList + 1) * 64;
+              osure = INT32_MIN;
+              oqbest = -1;
+              stop = true;
+            } else {
+              uint4 inf = make_uint4(0, 0, 0, 0);
+              if (is_cand) {
+                inf = S.einfo[idx];
+                cand[oat + 64u * (uint32_t) rank_below(cm)] = inf.x;
+              }
+              const int c0 = __builtin_ctzll(cm);
+              const bool settles = fill == 0 && nc == 1 && ((__ballot(certain) >> c0) & 1);
+              osure = settles ? bcast(e.y0, c0) : INT32_MIN;
+              oeid = settles ? (uint32_t) bcast((int32_t) inf.y, c0) : oeid;
+              oface = settles ? (uint32_t) bcast((int32_t) inf.z, c0) : oface;
+              oat += 64u * nc;
+            }
+          }
+          oj += 64;
+        }
+        if (lane == o) {
+          qbest[p] = oqbest; sure_y0[p] = osure; cand_at[p] = oat; sure_eid[p] = oeid; sure_face[p] = oface;
+          j[p] = jend[p];
+        }
+        wave_lds_fence();
+      }
+    }
+    if (STATS && A.stats) {
+      // [0] groups, [1] trips of the waves (a trip = one read per point set), [2] entries read, [3] of them ending below
+      // the point, [4] the longest scan of any point, [5..12] points by scan length: 0, <= 2, <= 4, <= 8, <= 16, <= 32, <= 64, more
+      if (lane == 0) { atomicAdd(&A.stats[0], 1ull); atomicAdd(&A.stats[1], (unsigned long long) st_iter); atomicAdd(&A.stats[13], (unsigned long long) st_coop); }
+#pragma unroll
+      for (int p = 0; p < PTS; p++) {
+        if (!valid[p]) continue;
+        atomicAdd(&A.stats[2], (unsigned long long) st_len[p]);
+        atomicAdd(&A.stats[3], (unsigned long long) st_below[p]);
+        atomicMax(&A.stats[4], (unsigned long long) st_len[p]);
+        const uint32_t n = st_len[p];
+        const int bin = n == 0 ? 0 : n <= 2 ? 1 : n <= 4 ? 2 : n <= 8 ? 3 : n <= 16 ? 4 : n <= 32 ? 5 : n <= 64 ? 6 : 7;
+        atomicAdd(&A.stats[5 + bin], 1ull);
+      }
     }
     // hand-over, per point set: exactly k_pip_walk's
 #pragma unroll
@@ -306,11 +407,12 @@ hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, in
   // (measured, first pass alone: 2.68 -> 2.42 ms on the lake-shaped base, 4.66 -> 4.01 lakes x parks; four per lane --
   //  86 VGPRs, 5 waves per SIMD -- 3.27 / 5.66: the pass is bound by the number of random reads, not by their latency)
   const uint64_t resident_waves = (uint64_t) cus * 32;
-  const int pts = a.n >= resident_waves * 2 * 128 ? 2 : 1;
+  const int pts = a.stats || a.n >= resident_waves * 2 * 128 ? 2 : 1;  // (the instrumented build is the two-point one)
   const uint64_t ngroups = (a.n + (uint64_t) pts * 64 - 1) / ((uint64_t) pts * 64);
   int grid = blocks_for(ngroups, 4, cus * 8);
   if (grid > max_blocks) grid = max_blocks;
   strip_note_grid = grid; strip_note_pts = pts;
+  if (a.stats) { hipLaunchKernelGGL((k_pip_strip<2, true>), dim3(grid), dim3(256), 0, st, a); return hipGetLastError(); }  // (the instrumented build: "stats" 1 + "pip_walk" 2)
   if (pts == 2) hipLaunchKernelGGL(k_pip_strip<2>, dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_pip_strip<1>, dim3(grid), dim3(256), 0, st, a);
   return hipGetLastError();

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     if "onesweep" in name or "radix" in name:
         return "rocprim_radix_sort"
-    m = re.search(r"rj::(k_[a-z_0-9]+)", name)
+    m = re.search(r"rj::(?:\(anonymous namespace\)::)?(k_[a-z_0-9]+)", name)
     if m:
         return m.group(1)
     return name.split("(")[0][:40]

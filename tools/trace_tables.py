@@ -12,7 +12,7 @@ ap.add_argument("--skip", type=int, default=0, help="ignore the last K step open
 a = ap.parse_args()
 rows = []
 for r in csv.DictReader(open(a.csv)):
-    m = re.search(r"rj::(k_[a-z_0-9]+)", r["Kernel_Name"])
+    m = re.search(r"rj::(?:\(anonymous namespace\)::)?(k_[a-z_0-9]+)", r["Kernel_Name"])
     name = m.group(1) if m else r["Kernel_Name"].split("(")[0].split("<")[0][-34:]
     wg = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 256)) or 256)
     grid = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)
