@@ -1901,6 +1901,7 @@ __host__ __device__ __forceinline__ size_t walk2_wave_lds(int top, int P = 2) { 
 // (96 SGPRs: above that the hardware admits one block per CU fewer than the occupancy query reports, and the shared
 //  schedule's walk + k_lsi2 blocks per CU no longer fit -- the skyline pointer took it to 100: 0.785 -> 0.852 ms.
 //  256 threads x 9 blocks: the compiler then aims below 57 VGPRs -- at 56, six blocks fit beside two of k_lsi2's 80)
+constexpr int kWalkCycleStamps = 7777;  // "stack_cap" value that turns the instrumented walk's counters into cycle stamps (tools/walk_stats_probe.py --cycles)
 template <bool STATS, int P>
 __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
   extern __shared__ uint4 walk_smem[];
@@ -1925,9 +1926,17 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
   // STATS (the instrumented build, rj_set_option "stats" 1 + "pip_walk" 2): what a 128-position group costs, per wave
   unsigned long long st_pops = 0, st_stale = 0, st_nodes = 0, st_leaf = 0, st_setvisits = 0, st_steps = 0, st_pushed = 0, st_sweeps = 0, st_swept = 0,
                      st_groups = 0, st_want = 0, st_hits = 0, st_rest = 0;
+  // ... and, with "stack_cap" set to kWalkCycleStamps, where a wave's cycles go instead (s_memtime stamps around the
+  // phases; the waits for memory are made explicit so that they are charged to the phase that needs the data)
+  const bool cyc = STATS && A.stack_cap == kWalkCycleStamps;
+  long long ck_sched = 0, ck_load = 0, ck_head = 0, ck_pop = 0, ck_node_wait = 0, ck_node = 0, ck_leaf_wait = 0, ck_leaf = 0, ck_bound = 0, ck_tail = 0;
+  const long long ck_begin = STATS ? clock64() : 0;
+#define RJ_CK(var, since) do { if (STATS && cyc) { const long long _n = clock64(); var += _n - since; since = _n; } } while (0)
   for (;;) {
     uint32_t g32 = 0;
+    long long ck = STATS && cyc ? clock64() : 0;
     if (!next_group<4>(ranges, wib, A.work_counter, nchunks, A.chunk_groups, ngroups, part, tried, lane, g32)) break;
+    RJ_CK(ck_sched, ck);
     typedef long long ll2_t __attribute__((ext_vector_type(2)));
     int32_t qx[P], qy[P], qbest[P], sure_y0[P];
     uint32_t cand_base[P], cand_at[P];
@@ -1949,6 +1958,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
     for (int p = 0; p < P; p++) ptl[p] = __builtin_nontemporal_load(reinterpret_cast<const ll2_t*>(A.pts) + ipl[p]);
     const QBox root_box = T.lvl[T.top][lane];
     const uint64_t root_higher = sibling_order(T, T.top)[lane];
+    if (STATS && cyc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RJ_CK(ck_load, ck); }
 #pragma unroll
     for (int p = 0; p < P; p++) {
       qx[p] = valid[p] ? quant(ptl[p].x) : 0;
@@ -2010,6 +2020,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
       wave_lds_fence();
       if (STATS) { st_groups++; st_pushed += (unsigned long long) sp; }
     }
+    RJ_CK(ck_head, ck);
     while (sp > 0) {
       --sp;
       uint4 ent;
@@ -2028,8 +2039,10 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
       }
       if (!__ballot(want_any)) {  // stale: untouched
         if (STATS) st_stale++;
+        RJ_CK(ck_pop, ck);
         continue;
       }
+      RJ_CK(ck_pop, ck);
       const uint32_t e = __builtin_amdgcn_readfirstlane(ent.x);
       const int lvl = (int) (e >> 28);
       const uint32_t idx = e & 0x0FFFFFFFu;
@@ -2038,6 +2051,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         asm volatile("" : "+v"(lane_here));
         const QBox b = T.lvl[lvl - 1][(uint64_t) idx * 64 + lane_here];
         const uint64_t higher = sibling_order(T, lvl - 1)[(uint64_t) idx * 64 + lane_here];
+        if (STATS && cyc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RJ_CK(ck_node_wait, ck); }
         if (gbest_stale) {  // (while the boxes are on their way)
           gbest_stale = false;
           int32_t lane_best = qbest[0] > qbest[1] ? qbest[0] : qbest[1];
@@ -2053,6 +2067,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         sp += __popcll(m);
         wave_lds_fence();
         if (STATS) { st_nodes++; st_pushed += (unsigned long long) __popcll(m); }
+        RJ_CK(ck_node, ck);
       } else {
         if (STATS) st_leaf++;
         const uint32_t slot0 = idx * 64;
@@ -2062,6 +2077,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         asm volatile("" : "+v"(lane_here));
         const QBox bb = T.box0[(uint64_t) slot0 + lane_here];  // one base segment per lane, sorted by x0
         const uint2 tab = T.xtab[(uint64_t) slot0 + lane_here];
+        if (STATS && cyc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RJ_CK(ck_leaf_wait, ck); }
         const uint32_t sx0s = __builtin_amdgcn_readfirstlane((uint32_t) ex0);
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
         bool changed = false;
@@ -2113,6 +2129,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
           }
           changed = changed || qbest[p] != qbest_before;
         }
+        RJ_CK(ck_leaf, ck);
         // (the group's bound is what a node expansion filters its pushes by and what a sweep drops entries by: with at
         //  most one entry left neither may ever happen again -- the reduction waits until an expansion asks for it)
         if (__ballot(changed)) gbest_stale = true;
@@ -2142,8 +2159,10 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
             wave_lds_fence();
           }
         }
+        RJ_CK(ck_bound, ck);
       }
     }
+    RJ_CK(ck_bound, ck);  // (what is left of the last iteration: the bound's reduction and sweeps are charged here and below)
     // hand-over, per set: exactly k_pip_walk's.  The gathers of the settled points -- edge id and face id under the one
     // candidate -- are all requested first (a lane without a hit reads slot 0: no branch around a load) and stored last,
     // behind the lists and masks: one memory round trip at the end of a group instead of 2 P.
@@ -2194,6 +2213,27 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
       }
     }
     wave_lds_fence();  // (the lists are reused by the next group)
+    if (STATS && cyc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RJ_CK(ck_tail, ck); }
+  }
+#undef RJ_CK
+  if (STATS && A.stats && cyc) {
+    if (lane == 0) {
+      const long long total = clock64() - ck_begin;
+      atomicAdd(&A.stats[0], (unsigned long long) total);
+      atomicAdd(&A.stats[1], (unsigned long long) ck_sched);
+      atomicAdd(&A.stats[2], (unsigned long long) ck_load);
+      atomicAdd(&A.stats[3], (unsigned long long) ck_head);
+      atomicAdd(&A.stats[4], st_groups);
+      atomicAdd(&A.stats[5], (unsigned long long) ck_pop);
+      atomicAdd(&A.stats[6], (unsigned long long) ck_node_wait);
+      atomicAdd(&A.stats[7], (unsigned long long) ck_node);
+      atomicAdd(&A.stats[8], (unsigned long long) ck_leaf_wait);
+      atomicAdd(&A.stats[9], (unsigned long long) ck_leaf);
+      atomicAdd(&A.stats[10], (unsigned long long) ck_bound);
+      atomicAdd(&A.stats[11], (unsigned long long) ck_tail);
+      atomicAdd(&A.stats[12], 1ull);  // waves
+    }
+    return;
   }
   if (STATS && A.stats) {
     // (per lane: st_hits is counted by one lane of each hit; everything else is wave-uniform and reported by lane 0)

@@ -10,6 +10,7 @@ from rayjoin_amd import _capi, maps, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--base", default="USCounty"); ap.add_argument("--query", default="BlockGroup")
 ap.add_argument("--scale", type=float, default=1.0); ap.add_argument("--walk-points", type=int, default=2)
+ap.add_argument("--cycles", action="store_true", help="cycle stamps of the phases instead of the event counts"); ap.add_argument("--max-blocks", type=int, default=0)
 a = ap.parse_args()
 ctx = maps.Context([synth.standin(a.base, a.scale), synth.standin(a.query, a.scale)]).load()
 b, q = ctx.maps
@@ -24,7 +25,19 @@ ms = []
 for _ in range(4):
     h.pip_query(0, 1, None, 0, n, closest, faces)
     ms.append((h.last_ms(_capi.RJ_T_PIP_WALK), h.last_ms(_capi.RJ_T_PIP_KERNEL)))
+if a.max_blocks:
+    h.set_debug_option("max_blocks", a.max_blocks)
 h.set_option("stats", 1)
+if a.cycles:
+    h.set_debug_option("stack_cap", 7777)  # kWalkCycleStamps
+    h.pip_query(0, 1, None, 0, n, closest, faces)
+    st = h.last_stats_raw()
+    names = ["total", "scheduler", "first_loads_wait", "bound_and_root", None, "pops", "node_wait", "node", "leaf_wait", "leaf_scan", "bound_and_sweeps", "hand_over"]
+    g, waves = st[4], st[12]
+    print(json.dumps({"pair": "%s x %s" % (a.base, a.query), "blocks": a.max_blocks or "full grid", "waves": waves, "groups": g,
+                      "cycles_per_group_of_a_wave": {k: round(st[i] / g) for i, k in enumerate(names) if k},
+                      "share": {k: round(st[i] / st[0], 3) for i, k in enumerate(names) if k and k != "total"}}))
+    sys.exit(0)
 h.pip_query(0, 1, None, 0, n, closest, faces)
 st = h.last_stats_raw() if hasattr(h, "last_stats_raw") else None
 names = {0: "leaf_blocks", 1: "rest_points", 2: "nodes_expanded", 3: "scan_steps", 4: "groups", 5: "leaf_set_visits", 6: "hit_bodies",
