@@ -41,6 +41,15 @@ def test_committed_bench_line_has_the_contract_fields():
         assert d["pip_caller_array"]["equals_map_owned_results"] is True and d["pip_caller_array"]["vs_map_owned"] < 1.06
     for s in d["secondary"]:
         assert s["value"] > 0 and "roofline" in s and "cpu_baseline" in s and s["config"]["schedule_settled_before_timing"] is True
+    if len(d["secondary"]) > 3:   # round 5: the pair with the published intersection density, the handle's plan, the ranks that ran
+        z = d["secondary"][3]
+        assert z["metric"].split(", ")[1] == "USCounty |><| CrossingZipcode"
+        assert 0.030 < z["intersections_per_query_segment"] < 0.040   # County x Zipcode in the reference's log: 0.0351
+        assert d["plan"]["schedule"]["settled"] and d["plan"]["lsi"]["kernel"].startswith("k_lsi") and d["plan"]["pip"]["passes"] in (1, 3)
+        assert d["ranks"]["world_size"] == d["n_gpus"] == 1
+        ring = d["secondary"][2]["roofline"]
+        assert ring["kernel"] == "k_pip_strip" and ring["traffic"] and ring["traffic"] > ring["algorithmic_bytes"]   # its own section of traffic.json
+        assert d["roofline"]["on_its_share_of_the_chip"]["valu_per_query"] > 0
 
 
 def test_no_schedule_trials_inside_the_timed_region():
