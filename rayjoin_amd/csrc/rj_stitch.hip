@@ -206,12 +206,18 @@ hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t
     if ((e = hipMemsetAsync(in_loop, 0, nc, st)) != hipSuccess) break;
     // 1. end points -> keys; 2. sort by y, then stably by x; pair every junction
     hipLaunchKernelGGL(k_st_end_keys, dim3(B > 2048 ? 2048 : B), dim3(kThreads), 0, st, ni, pts, eb, kx, ky, dir, va, meta);
+    // (a map of closed rings has nothing to pair -- a ring's ends never take part -- and the two sorts of its 2 nc chain
+    //  ends were half of this stage on the lake-shaped maps: one more look at the count decides)
+    if ((e = hipMemcpyAsync(&hm, meta, sizeof(Meta), hipMemcpyDeviceToHost, st)) != hipSuccess) break;
+    if ((e = hipStreamSynchronize(st)) != hipSuccess) break;
     size_t tb = temp_bytes;
-    if ((e = rocprim::radix_sort_pairs(temp, tb, ky, ska, va, vb, (size_t) ni, 0, kKeyBits, st)) != hipSuccess) break;
-    hipLaunchKernelGGL(k_st_gather_keys, dim3(B), dim3(kThreads), 0, st, ni, kx, vb, skb);
-    tb = temp_bytes;
-    if ((e = rocprim::radix_sort_pairs(temp, tb, skb, ska, vb, va, (size_t) ni, 0, kKeyBits, st)) != hipSuccess) break;
-    hipLaunchKernelGGL(k_st_pair, dim3(B), dim3(kThreads), 0, st, ni, ska, va, ky, dir, partner);
+    if (hm.closed_chains != nc) {
+      if ((e = rocprim::radix_sort_pairs(temp, tb, ky, ska, va, vb, (size_t) ni, 0, kKeyBits, st)) != hipSuccess) break;
+      hipLaunchKernelGGL(k_st_gather_keys, dim3(B), dim3(kThreads), 0, st, ni, kx, vb, skb);
+      tb = temp_bytes;
+      if ((e = rocprim::radix_sort_pairs(temp, tb, skb, ska, vb, va, (size_t) ni, 0, kKeyBits, st)) != hipSuccess) break;
+      hipLaunchKernelGGL(k_st_pair, dim3(B), dim3(kThreads), 0, st, ni, ska, va, ky, dir, partner);
+    }
     // 3. list ranking
     hipLaunchKernelGGL(k_st_rank_init, dim3(B), dim3(kThreads), 0, st, ni, partner, eb, n0, n1);
     for (int r = 0; r < rounds; r++)
