@@ -284,7 +284,6 @@ struct rj_handle_s {
       const char* why = "";
     } pip;
   } plan;
-  std::string plan_text;
   std::string err;
 };
 
@@ -711,7 +710,6 @@ int rj_get_plan(rj_handle h, char* buf, size_t cap, size_t* need) {
     add(", \"pip\": null");
   }
   o += "}";
-  h->plan_text = o;
   if (need) *need = o.size();
   if (buf && cap) {
     const size_t k = o.size() < cap - 1 ? o.size() : cap - 1;
