@@ -147,7 +147,10 @@ def load():
             raise ImportError("rayjoin_amd: %s is missing -- build the HIP extension first "
                               "(make -C rayjoin_amd/csrc); there is no CPU fallback" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        variant = bool(os.environ.get("RAYJOIN_AMD_LIB"))  # an A/B build of another revision may lack the newer entry points
         for name, (res, args) in SYMBOLS.items():
+            if variant and not hasattr(L, name):
+                continue
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args

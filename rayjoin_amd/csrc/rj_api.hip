@@ -129,10 +129,15 @@ struct rj_handle_s {
   int co_wpc = 8;  // walk blocks a CU can hold for the base tree of the pair being scheduled
   int lsi_share_set = 0, pip_share_set = 0;  // "lsi_share_set" / "pip_share_set": fixed grids for schedule 1 (0 = derive them, the default)
   int co_L = 0, co_best_L = 0;  // the k_lsi grid of the next shared pair / of the best one measured (0: the formula below)
+  float co_best_imb = 0;        // ... and how far apart its two sides ended, as a fraction of its span
   int lsi_share_blocks() const {
     if (lsi_share_set) return lsi_share_set;
     if (co_L) return co_L;
-    const int b = ((int) ((512.0f + 128.0f * (float) (8 - co_wpc) + 200.0f * (co_ratio - 0.6f)) * (float) cus / 256.0f) + 32) / 64 * 64;
+    // (in steps of half a block per CU since round 5: at 2.25 blocks per CU a quarter of the CUs hold a third k_lsi2 block
+    //  and one walk block less than fits -- the nested pair at 448 / 512 / 576 / 640 blocks: 1.34 / 1.29 / 1.44 / 1.30 ms --
+    //  and a fit that lands on either side of such a step from run to run is not a schedule)
+    const int half = cus / 2 > 0 ? cus / 2 : 1;
+    const int b = ((int) ((512.0f + 128.0f * (float) (8 - co_wpc) + 200.0f * (co_ratio - 0.6f)) * (float) cus / 256.0f) + half / 2) / half * half;
     return b < cus ? cus : (b > cus * 4 ? cus * 4 : b);
   }
   int last_pip_share = 0;  // the PIP side's grid in the last shared pair (what "pip_share_blocks" reports)
@@ -379,6 +384,7 @@ static void co_reset(rj_handle h) {
   h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0; h->co_np = 0;
   h->co_ratio = 0.46f;
   h->co_L = h->co_best_L = 0;
+  h->co_best_imb = 0;
 }
 static void co_collect(rj_handle h) {  // read the span of the previous pair, if it has completed
   if (!h->co_measure) return;
@@ -403,14 +409,19 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
     // pair of a workload -- so the second shared trial corrects it by what the first one showed: the side that ended
     // later gets more of the chip.
     const int used = h->lsi_share_blocks();
-    // (the neighbour has to win by 3 % -- one sample's noise plus what the first shared pair of a workload pays for
-    //  being the first: near a tie the grid the sweep's fit gives stays)
-    if (h->co_best_L == 0 || span < h->co_best[1] * 0.97f) h->co_best_L = used;
     const float lsi_side = a > c ? a : c;
     const float imb = (lsi_side - b) / (span > 0 ? span : 1.0f);
-    // (one 64-block step: the landscape is flat to 1-3 % per step around the best grid, and a measured neighbour is worth
-    //  more than an extrapolated one)
-    int next = used + (imb > 0 ? 64 : -64) * h->cus / 256;
+    // Which of the two shared grids stays: the neighbour has to win by 3 % -- one sample's noise plus what the first shared
+    // pair of a workload pays for being the first: near a tie the grid the sweep's fit gives stays -- or by 1 % if its two
+    // sides also end closer together (round 5: the span alone left the nested pair on 576 or 512 blocks from run to run,
+    // 1.45 or 1.31 ms per step; balance alone took the headline to 448 + 1 792, whose pipelined step is 4 % slower).
+    const float aimb = imb < 0 ? -imb : imb;
+    if (h->co_best_L == 0 || span < h->co_best[1] * 0.97f || (span < h->co_best[1] * 0.99f && aimb < h->co_best_imb)) {
+      h->co_best_L = used;
+      h->co_best_imb = aimb;
+    }
+    // (one step of half a block per CU: a measured neighbour is worth more than an extrapolated one)
+    int next = used + (imb > 0 ? 1 : -1) * (h->cus / 2 > 0 ? h->cus / 2 : 1);
     next = next < h->cus ? h->cus : (next > h->cus * 4 ? h->cus * 4 : next);
     h->co_L = next;
   }
@@ -418,6 +429,9 @@ static void co_collect(rj_handle h) {  // read the span of the previous pair, if
   if (++h->co_trials >= kCoTrials && h->co_choice < 0) {
     h->co_choice = 0;
     for (int m = 1; m < 3; m++) if (h->co_best[m] < h->co_best[h->co_choice]) h->co_choice = m;
+    // (one sample per schedule: within 3 % of the best, sharing stays -- it is the schedule both kernels were shaped for,
+    //  and the one whose pairs were measured twice)
+    if (h->co_choice != 1 && h->co_best[1] <= h->co_best[h->co_choice] * 1.03f) h->co_choice = 1;
     if (h->co_best_L) h->co_L = h->co_best_L;  // (the split of the best shared pair stays)
     h->plan.sched_epoch = h->plan.epoch;
   }
