@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-scale", type=float, default=1.0)
     ap.add_argument("--check", action="store_true", help="size-independent result checks after timing")
+    ap.add_argument("--exact-stream", action="store_true", help="pipelined steps: the PIP query's exact kernel on a stream of its own (\"pip_exact_stream\"; measured: no gain, see DESIGN.md section 5 -- for A/B runs)")
     ap.add_argument("--no-gather-pip", action="store_true", help="N>1: leave the PIP result queues with their shards (round-2 behaviour)")
     ap.add_argument("--gather-pip", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--serial-kernels", action="store_true", help="run the PIP kernels after the LSI kernel instead of beside it")
@@ -166,6 +167,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     #  looked at step k's count)
     closest2 = [torch.empty(max_pts, dtype=torch.int32, device=dev) for _ in range(2)]
     faces = torch.empty(max_pts, dtype=torch.int32, device=dev)
+    faces2 = [faces, torch.empty(max_pts, dtype=torch.int32, device=dev)]
     xsects = torch.empty((cap, 6), dtype=torch.int64, device=dev)  # dev::Intersection<int64_t>, 48 B each
     if world > 1:
         # count + pairs leave in ONE all-gather on the handle's communication stream, overlapped with the PIP kernels:
@@ -260,6 +262,9 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     # step j - 1's PIP queue is gathered behind step j's kernels.  Every step's results are complete and looked at
     # inside the timed region (the closing barrier waits for the last).
     def pipelined_steps(k, with_gather=True):
+        # (--exact-stream: the exact kernel of step k's PIP query on its own stream, beside step k + 1's walk --
+        #  include/rayjoin_amd.h "pip_exact_stream"; both of the query's outputs are double-buffered for it)
+        h.set_option("pip_exact_stream", 1 if args.exact_stream else 0)
         barrier()
         h.set_option("timers", 0)
         t0 = time.perf_counter()
@@ -272,14 +277,14 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                 early = h.get_option("pip_schedule") in (1, 2)
             h.lsi_query_async(0, 1, e0, e1, cap, pairs2[b])
             if early:
-                h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+                h.pip_query(0, 1, None, p0, p1 - p0, closest, faces2[b], sync=False)
             h.lsi_points_async(pairs2[b], cap, xsects)
             if world > 1:
                 ex.begin(b)
             else:
                 h.lsi_count_async(b)
             if not early:
-                h.pip_query(0, 1, None, p0, p1 - p0, closest, faces, sync=False)
+                h.pip_query(0, 1, None, p0, p1 - p0, closest, faces2[b], sync=False)
             if pg is not None and with_gather:
                 pg.begin(closest)   # (waits, on the host, for the gather of step j - 1: its buffer is step j + 1's)
             if j > 0:
@@ -298,6 +303,9 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         barrier()
         el = time.perf_counter() - t0
         h.set_option("timers", 1)
+        h.set_option("pip_exact_stream", 0)
+        if b:
+            faces.copy_(faces2[1])
         state["timers_on"] = True
         state["n"] = n
         state["closest"] = closest2[b]

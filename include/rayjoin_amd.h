@@ -332,6 +332,13 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  *                                             chip (a caller that issues one kind of query).  The PIP query's inputs must
  *                                             be complete when the call is made; its outputs are complete after rj_sync,
  *                                             rj_pip_query or rj_last_ms(RJ_T_PIP_KERNEL).
+ * "pip_exact_stream" 0 / 1                    for a caller that keeps several steps in flight (step k + 1 issued before
+ *                                             step k's results are read): the exact kernel of a PIP query that runs on
+ *                                             the handle's second stream (see "pip_concurrent") goes to a third stream
+ *                                             behind its walk, so the NEXT query's walk starts beside it instead of after
+ *                                             it.  Consecutive asynchronous PIP queries must then write to DIFFERENT
+ *                                             output arrays (a pipelined caller double-buffers them anyway: step k's
+ *                                             answers are still being read); which kernels ran is unchanged.
  * "timers"           1 / 0                    record the stage timers behind rj_last_ms (two event records per stage,
  *                                             ~1 % of a 0.9 ms step); while "pip_concurrent" 2 is still trying schedules
  *                                             they are recorded regardless.

@@ -156,10 +156,23 @@ struct rj_handle_s {
   int last_walk_points = 1;                // ... and how many points a lane of its walk took
   int last_passes = 0;                     // kernels of the last PIP query (3 or 1)
   int flip_walk[2] = {0, 0};
-  uint32_t* rest[2] = {nullptr, nullptr};  // per stream (main / aux): points the walk left to k_pip (grow-only)
-  uint64_t rest_cap[2] = {0, 0};
-  uint32_t* todo[2] = {nullptr, nullptr};  // per stream: candidate lists the walk left to k_pip_exact, one slot per query position (grow-only)
-  unsigned long long* todo_mask[2] = {nullptr, nullptr};  // ... and which slots of a group are filled
+  // list sets: [0] main stream, [1] aux, [2] aux again -- "pip_exact_stream" alternates [1] and [2], so that the walk of
+  // query k + 1 fills one set while the exact kernel of query k, on its own stream, still reads the other
+  uint32_t* rest[3] = {nullptr, nullptr, nullptr};  // points the walk left to k_pip (grow-only)
+  uint64_t rest_cap[3] = {0, 0, 0};
+  uint32_t* todo[3] = {nullptr, nullptr, nullptr};  // candidate lists the walk left to k_pip_exact, one slot per query position (grow-only)
+  unsigned long long* todo_mask[3] = {nullptr, nullptr, nullptr};  // ... and which slots of a group are filled
+  // "pip_exact_stream" 1: the exact kernel of a PIP query on the aux stream runs on a third stream, behind its walk by an
+  // event -- the walk of the NEXT query (aux stream) starts while it runs instead of after it.  Three rest-count words in
+  // rotation (a walk clears the next one's: the one after that may still be read by the exact kernel two queries back,
+  // which the walk waits for -- it is also the last reader of the list set the walk is about to fill).
+  int exact_own_stream = 0;
+  hipStream_t exact_stream = nullptr;
+  hipEvent_t ev_walk_done = nullptr, ev_exact_done[2] = {nullptr, nullptr};
+  bool exact_recorded[2] = {false, false};  // ev_exact_done[b] has been recorded at least once
+  int exact_buf = 0, exact_last = -1;       // the list set (1 + exact_buf) the next such query uses; the one the last used
+  int exact_rot = 0;                        // ... and its rest-count word (kExactRestWord)
+  bool exact_pending = false;               // something was enqueued on exact_stream since it was last joined
   unsigned long long* h_rest = nullptr;    // mapped host words [0],[1]: the rest count of the last finished query per stream (a hint; [2]: see lsi_points_on_stream
   unsigned long long* d_rest = nullptr;    // for the next launch's grid and for "pip_rest"; the same memory as the device sees it)
   uint64_t walk_n[2] = {0, 0};             // size of the query the hint belongs to
@@ -375,7 +388,13 @@ void toc(rj_handle h, int t, hipStream_t st = nullptr) { if (timers_off(h)) retu
 hipError_t join_aux(rj_handle h) {
   if (!h->aux_pending) return hipSuccess;
   h->aux_pending = false;
-  return hipStreamSynchronize(h->aux_stream);
+  hipError_t e = hipStreamSynchronize(h->aux_stream);
+  if (h->exact_pending) {
+    h->exact_pending = false;
+    const hipError_t e2 = hipStreamSynchronize(h->exact_stream);
+    if (e == hipSuccess) e = e2;
+  }
+  return e;
 }
 
 // ---- "pip_concurrent" 2: which schedule for this pair? ------------------------------------------
@@ -459,6 +478,7 @@ constexpr size_t kSchedWalkMain = kSchedPipAux + 2 * kSchedBlockWords, kSchedWal
 constexpr size_t kCounterBytes = (kSchedWalkAux + 2 * kSchedBlockWords) * 8;
 constexpr size_t kSlowCountWord = 12;    // [12],[13] (alternating): how many pairs k_lsi_points left to k_lsi_points_gcd
 constexpr size_t kRestCountWord = 8;     // [8],[9] main stream (alternating), [10],[11] aux: how many points k_pip_walk left to k_pip
+constexpr size_t kExactRestWord[3] = {10, 11, 14};  // ... the aux stream's under "pip_exact_stream": three in rotation
 constexpr size_t kGridLsiCountWord = 6;  // rj_lsi_query_grid's result count (cleared by a fill: not on the hot path)
 
 // after a stream sync: did a traversal stack overflow?  (cannot for an index rj_build_lbvh accepted)
@@ -496,6 +516,13 @@ int rj_create(int device_id, rj_handle* out) {
   if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { delete h; return RJ_E_HIP; }
   h->stream = h->own_stream;
   if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess) { (void) hipStreamDestroy(h->own_stream); delete h; return RJ_E_HIP; }
+  // (highest priority: its blocks are short and few -- they take the slots a draining walk frees before the next walk's do,
+  //  instead of waiting behind a chip full of the next walk's resident blocks)
+  int prio_least = 0, prio_greatest = 0;
+  (void) hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (hipStreamCreateWithPriority(&h->exact_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess) {
+    (void) hipStreamDestroy(h->own_stream); (void) hipStreamDestroy(h->aux_stream); delete h; return RJ_E_HIP;
+  }
   bool ok = hipMalloc((void**) &h->d_counter, kCounterBytes) == hipSuccess &&
             hipMalloc((void**) &h->d_stats, 128) == hipSuccess &&
             hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess &&
@@ -521,6 +548,9 @@ int rj_create(int device_id, rj_handle* out) {
   ok = ok && hipEventCreateWithFlags(&h->ev_count[0], hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&h->ev_count[1], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&h->ev_order, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&h->ev_walk_done, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->ev_exact_done[0], hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&h->ev_exact_done[1], hipEventDisableTiming) == hipSuccess;
   // load every code object of the library now (a kernel's first launch loads its file's code object: milliseconds
   // that would otherwise land in the first upload, the first index build and the first query)
   ok = ok && warm_query_kernels(h->stream) == hipSuccess && warm_grid_kernels(h->stream) == hipSuccess &&
@@ -536,22 +566,26 @@ int rj_destroy(rj_handle h) {
   (void) hipSetDevice(h->device);
   (void) hipStreamSynchronize(h->stream);
   (void) hipStreamSynchronize(h->aux_stream);
+  (void) hipStreamSynchronize(h->exact_stream);
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
   for (int k = 0; k < 2; k++) for (int i = 0; i < 2; i++) (void) hipFree(h->ordc[k][i].perm);
   (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
   (void) hipFree(h->slow_list);
   (void) hipHostFree(h->h_est);
   for (int k = 0; k < rj_handle_s::kCallerSets; k++) (void) hipFree(h->caller[k].perm);
-  (void) hipHostFree(h->h_rest); (void) hipFree(h->rest[0]); (void) hipFree(h->rest[1]); (void) hipFree(h->todo[0]); (void) hipFree(h->todo[1]); (void) hipFree(h->todo_mask[0]); (void) hipFree(h->todo_mask[1]);
+  (void) hipHostFree(h->h_rest); for (int k = 0; k < 3; k++) { (void) hipFree(h->rest[k]); (void) hipFree(h->todo[k]); (void) hipFree(h->todo_mask[k]); }
   (void) hipFree(h->ord_kin); (void) hipFree(h->ord_kout); (void) hipFree(h->ord_vin); (void) hipFree(h->ord_vout); (void) hipFree(h->ord_temp);
   for (int t = 0; t < kNumTimers; t++) { (void) hipEventDestroy(h->ev[t][0]); (void) hipEventDestroy(h->ev[t][1]); }
   for (int k = 0; k < 2; k++) if (h->ev_count[k]) (void) hipEventDestroy(h->ev_count[k]);
   if (h->ev_order) (void) hipEventDestroy(h->ev_order);
+  if (h->ev_walk_done) (void) hipEventDestroy(h->ev_walk_done);
+  for (int k = 0; k < 2; k++) if (h->ev_exact_done[k]) (void) hipEventDestroy(h->ev_exact_done[k]);
   (void) hipFree(h->arena);
   (void) hipFree(h->strip_scratch);
   if (h->comm) (void) rj_comm_destroy(h);
   (void) hipStreamDestroy(h->own_stream);
   (void) hipStreamDestroy(h->aux_stream);
+  (void) hipStreamDestroy(h->exact_stream);
   delete h;
   return RJ_OK;
 }
@@ -611,6 +645,7 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "pip_walk")) *value = h->pip_walk;
   else if (!strcmp(name, "timers")) *value = h->timers;
   else if (!strcmp(name, "pip_walk_points")) *value = h->walk_points;
+  else if (!strcmp(name, "pip_exact_stream")) *value = h->exact_own_stream;
   else if (!strcmp(name, "lsi_segments")) *value = h->lsi_segments;
   else if (!strcmp(name, "lsi_last_segments")) *value = h->last_lsi_segments;
   else if (!strcmp(name, "pip_last_walk_points")) *value = h->last_walk_points;
@@ -768,6 +803,22 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
   if (!strcmp(name, "pip_walk_points")) {
     if (value != 1 && value != 2 && value != 4) return fail(h, RJ_E_INVALID, "pip_walk_points: 1, 2 or 4");
     h->walk_points = (int) value;
+    return RJ_OK;
+  }
+  if (!strcmp(name, "pip_exact_stream")) {
+    if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "pip_exact_stream: 0 or 1");
+    if ((int) value == h->exact_own_stream) return RJ_OK;
+    // the two modes keep the aux stream's rest counts in different words: drain, then start both from zeroed words
+    if (int r = set_device(h)) return r;
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    h->aux_pending = true;
+    RJ_HIP(h, join_aux(h));
+    RJ_HIP(h, hipStreamSynchronize(h->exact_stream));
+    for (size_t wd : kExactRestWord) RJ_HIP(h, hipMemsetAsync(h->d_counter + wd, 0, 8, h->stream));
+    RJ_HIP(h, hipStreamSynchronize(h->stream));
+    h->exact_rot = 0; h->exact_buf = 0; h->exact_last = -1;
+    h->exact_recorded[0] = h->exact_recorded[1] = false;
+    h->exact_own_stream = (int) value;
     return RJ_OK;
   }
   if (!strcmp(name, "timers")) {
@@ -1706,12 +1757,15 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     walk = false;
     why = "the last two-pass query of this size left too many points to the exact kernel (> 30 %, or > 16384): first pass dropped";
   }
-  if (walk && h->rest_cap[si] < n) {
+  // the exact kernel on its own stream ("pip_exact_stream"): list set 1 or 2, see the handle
+  const bool own = aux && walk && h->exact_own_stream;
+  const int li = own ? 1 + h->exact_buf : si;
+  if (walk && (h->rest_cap[si] < n || h->rest_cap[li] < n)) {
     // (both streams' lists at once, the first time a size is seen: a later query on the other stream -- the shared
     //  schedule's trial pair -- must not pay for an allocation inside its measured span)
     RJ_HIP(h, hipStreamSynchronize(h->stream));  // (the lists may still be in use by a query in flight)
     RJ_HIP(h, join_aux(h));
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < (h->exact_own_stream ? 3 : 2); k++) {
       if (h->rest_cap[k] >= n) continue;
       (void) hipFree(h->rest[k]); (void) hipFree(h->todo[k]); (void) hipFree(h->todo_mask[k]);
       h->rest[k] = nullptr; h->rest_cap[k] = 0; h->todo[k] = nullptr; h->todo_mask[k] = nullptr;
@@ -1735,10 +1789,17 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     PipArgs w = a;
     w.work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + wflip * kSchedBlockWords);
     w.next_work_counter = (unsigned int*) (h->d_counter + (aux ? kSchedWalkAux : kSchedWalkMain) + (1 - wflip) * kSchedBlockWords);
-    w.rest = h->rest[si];
+    w.rest = h->rest[li];
     w.rest_count = h->d_counter + kRestCountWord + 2 * si + wflip;
     w.next_rest_count = h->d_counter + kRestCountWord + 2 * si + (1 - wflip);
-    w.todo = h->todo[si]; w.todo_mask = h->todo_mask[si];
+    if (own) {
+      w.rest_count = h->d_counter + kExactRestWord[h->exact_rot];
+      w.next_rest_count = h->d_counter + kExactRestWord[(h->exact_rot + 1) % 3];
+      h->exact_rot = (h->exact_rot + 1) % 3;
+      // the exact kernel two queries back: the last reader of this list set, and of the count word this walk clears for the next
+      if (h->exact_recorded[h->exact_buf]) RJ_HIP(h, hipStreamWaitEvent(st, h->ev_exact_done[h->exact_buf], 0));
+    }
+    w.todo = h->todo[li]; w.todo_mask = h->todo_mask[li];
     if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
     // Two points per lane (k_pip_walk2: one traversal per 128 positions) where the query set is large enough for full
     // 64-position groups and nobody is counting visits: headline step -5.5 %, Zipcode -6 %, nested -5 %.  (The walk's
@@ -1774,7 +1835,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     //  to do with each other -- a handful of overflowed lists are unrelated traversals, one wave each)
     const uint64_t left = seen != ~0ull ? seen : 8192;
     PipRestArgs r;
-    r.order = h->rest[si];
+    r.order = h->rest[li];
     r.n_dev = w.rest_count;
     r.rest_count = h->d_rest + si;  // (the count goes to the host)
     r.work_counter = a.work_counter;
@@ -1789,12 +1850,25 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     }
     r.blocks = (uint32_t) rest_blocks;
     h->walk_n[si] = n;
-    RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8, r));
+    if (own) {
+      RJ_HIP(h, hipEventRecord(h->ev_walk_done, st));
+      RJ_HIP(h, hipStreamWaitEvent(h->exact_stream, h->ev_walk_done, 0));
+      RJ_HIP(h, launch_pip_exact(h->exact_stream, w, h->cus * 8, r));
+      RJ_HIP(h, hipEventRecord(h->ev_exact_done[h->exact_buf], h->exact_stream));
+      h->exact_recorded[h->exact_buf] = true;
+      h->exact_last = h->exact_buf;
+      h->exact_buf ^= 1;
+      h->exact_pending = true;
+    } else {
+      RJ_HIP(h, launch_pip_exact(st, w, h->cus * 8, r));
+    }
     h->flip_pip[si] = 1 - pflip;
     h->plan.pip.exact_blocks = h->cus * 8; h->plan.pip.locate_blocks = rest_blocks;
     if (columns) why = "the base map has a column index (a map of closed rings): the first pass reads the point's strip";
     else if (!two && h->walk_points >= 2) why = "one point per lane: a query set too small for full groups on every resident wave (or a debug knob set)";
   } else if (n) {
+    // (k_pip uses the scheduler block the last exact kernel of this stream used or cleared)
+    if (aux && h->exact_pending && h->exact_last >= 0) RJ_HIP(h, hipStreamWaitEvent(st, h->ev_exact_done[h->exact_last], 0));
     RJ_HIP(h, launch_pip(st, a, h->stats_on, max_blocks));
     h->flip_pip[aux ? 1 : 0] = 1 - pflip;
     h->plan.pip.first = last_launch();
@@ -1806,7 +1880,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     pp.shared = aux && h->lsi_shared; pp.passes = h->last_passes; pp.rest_hint = seen; pp.why = why;
     pp.order = order ? (h->order_fresh ? 2 : 1) : 0;
   }
-  toc(h, RJ_T_PIP_KERNEL, st);
+  toc(h, RJ_T_PIP_KERNEL, own ? h->exact_stream : st);
   // a caller-owned array: the estimate the next query over it will go by, behind this query's kernels on their stream
   // (the first queries after a sort or a first sight, then every fourth: one block, a few microseconds)
   if (h->cur_caller >= 0 && n) {
@@ -2207,6 +2281,7 @@ int rj_exchange_u32_begin(rj_handle h, const uint32_t* src_dev, uint64_t n_per_r
   RJ_HIP(h, hipStreamWaitEvent(cs, h->ev_comm2, 0));
   RJ_HIP(h, hipEventRecord(h->ev_comm2_aux, h->aux_stream));
   RJ_HIP(h, hipStreamWaitEvent(cs, h->ev_comm2_aux, 0));
+  if (h->exact_pending && h->exact_last >= 0) RJ_HIP(h, hipStreamWaitEvent(cs, h->ev_exact_done[h->exact_last], 0));  // ("pip_exact_stream")
   if (n_per_rank) RJ_NCCL(h, ncclAllGather(src_dev, recv_dev, n_per_rank, ncclUint32, c, cs));
   return RJ_OK;
 }
