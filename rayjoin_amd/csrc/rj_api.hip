@@ -1038,7 +1038,7 @@ static int ensure_sort_scratch(rj_handle h, uint64_t n) {
 // the column index of an index whose leaves are built (b.box0, b.seid): rj_strip.hip.  Temporaries come out of one
 // grow-only scratch block of the handle and the index's own arrays are kept while they are large enough: a rebuild
 // allocates nothing (the first version paid six hipMalloc / hipFree of hundreds of MB per build: 50-120 ms).
-static int build_strips(rj_handle h, BvhState& b) {
+static int build_strips(rj_handle h, BvhState& b, bool with_sky) {
   b.strips_built = false;
   auto up = [](size_t v) { return (v + 255) & ~(size_t) 255; };
   auto scratch = [&](size_t bytes) -> int {
@@ -1055,9 +1055,10 @@ static int build_strips(rj_handle h, BvhState& b) {
   const size_t cnt_bytes = up(4 * (b.n0p + 1));
   // pass 1 needs: cnt, offs, flag, scan temp; pass 2 adds key_tmp, slot_tmp, sort temp (sized once the total is known:
   // an upper bound first -- twice the slots covers every map whose segments are not wider than a strip or two)
-  if (int r = scratch(2 * cnt_bytes + 256 + up(scan_bytes))) return r;
-  RJ_HIP(h, launch_strip_width(h->stream, b.box0, b.seid, b.n0p, (unsigned long long*) h->strip_scratch));
-  RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 30, h->strip_scratch, 16, hipMemcpyDeviceToHost, h->stream));
+  // (the width's two sums land in d_counter[2],[3] -- the grid build's words, same stream -- so that the scratch block
+  //  can be sized once the strip count is known)
+  RJ_HIP(h, launch_strip_width(h->stream, b.box0, b.seid, b.n0p, h->d_counter + 2));
+  RJ_HIP(h, hipMemcpyAsync(h->h_pinned + 30, h->d_counter + 2, 16, hipMemcpyDeviceToHost, h->stream));
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   if (!h->h_pinned[31]) return RJ_OK;  // (no real segment)
   const double mean_dx = (double) h->h_pinned[30] / (double) h->h_pinned[31];
@@ -1065,6 +1066,17 @@ static int build_strips(rj_handle h, BvhState& b) {
   while (shift < kStripShiftMax && (double) (2u << shift) <= 2.3 * mean_dx) shift++;
   if (h->debug_strip_shift) shift = h->debug_strip_shift;
   const uint32_t strips = strip_count(shift);
+  {
+    // everything both passes need, for an estimate of 2 entries per slot (the lake-shaped maps have 1.5): the counts then
+    // stay where they are when the total arrives (a first build used to count and scan twice: 0.27 ms)
+    const size_t est = 2 * (size_t) b.n0p;
+    size_t est_sort = 0;
+    RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, b.n0p, shift, est, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, est_sort));
+    const size_t both = 2 * cnt_bytes + 256 + 2 * up(8 * est) + 2 * up(4 * est) + up(4 * (size_t) strips) + up(est_sort);
+    const size_t first = 2 * cnt_bytes + 256 + up(scan_bytes);
+    if (int r = scratch(both > first ? both : first)) return r;
+  }
   uint32_t* cnt = (uint32_t*) h->strip_scratch;
   uint32_t* offs = (uint32_t*) (h->strip_scratch + cnt_bytes);
   uint32_t* flag = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes);
@@ -1079,7 +1091,7 @@ static int build_strips(rj_handle h, BvhState& b) {
   if (bad || total == 0) return RJ_OK;  // (a segment spanning more than kStripMaxSpan strips: the tree alone serves this map)
   size_t sort_bytes = 0;
   RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, b.n0p, shift, total, nullptr, nullptr, nullptr, nullptr, nullptr,
-                              nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
+                              nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
   const size_t need = 2 * cnt_bytes + 256 + 2 * up(8 * (size_t) total) + 2 * up(4 * (size_t) total) + up(4 * (size_t) strips) + up(sort_bytes);
   if (need > h->strip_scratch_bytes) {
     // (the counts live in the scratch block that is about to move: count again into the new one -- first build of a
@@ -1113,8 +1125,11 @@ static int build_strips(rj_handle h, BvhState& b) {
     b.strip_tab_shift = shift;
   }
   tb = sort_bytes;
+  // (the skyline, where wanted, comes out of the same pass: every entry's box is in hand there)
+  if (with_sky) RJ_HIP(h, hipMemsetAsync(b.sky, 0, ((size_t) kSkyBuckets + 1) * 4, h->stream));
   RJ_HIP(h, launch_strip_fill(h->stream, b.box0, b.seid, b.sface, cnt, offs, b.n0p, shift, total, key, slot_sorted, key_tmp, slot_tmp, tall_tmp,
-                              b.strip_ytab, b.strip_box, b.strip_info, b.strip_tall, temp, tb));
+                              b.strip_ytab, b.strip_box, b.strip_info, b.strip_tall, with_sky ? b.sky : nullptr, temp, tb));
+  b.use_sky = with_sky;
   b.strip_shift = shift;
   b.strip_entries = total;
   b.strips_built = true;
@@ -1278,11 +1293,11 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     // to a third of its time (one atomic per segment and bucket) and every query point a load for nothing; a map of
     // isolated rings leaves a third of a lattice's vertices with nothing above them (35 % measured on the lake-shaped
     // stand-in, 240 leaf blocks opened for each).  So: built where most chains are closed rings.
-    b.use_sky = h->skyline == 1 || (h->skyline < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc);
-    if (b.use_sky && (e = hipMemsetAsync(b.sky, 0, ((size_t) kSkyBuckets + 1) * 4, h->stream)) != hipSuccess) break;
+    // (filled below: by the column index's own pass where the map gets one, else by a pass over the leaves' boxes)
+    b.use_sky = false;
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, nruns ? m.piece_begin : nullptr,
-                                 m.piece_len, m.run_first, m.leaf_first, b.n0p / 64, b.alloc[1],
-                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ, b.use_sky ? b.sky : nullptr)) != hipSuccess) break;
+                                 m.piece_len, m.run_first, m.run_len, m.leaf_first, b.n0p / 64, b.alloc[1],
+                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
     const QBox* child = b.lvl[1];
@@ -1302,8 +1317,14 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   // The column index (rj_device.h DeviceStrips), where the tree is at its worst for upward rays: maps of isolated rings
   // (the criterion of the skyline).  Two passes over the sorted slots around a radix sort of the (strip, y0) entries.
   b.strips_built = false;
+  const bool want_sky = h->skyline == 1 || (h->skyline < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc);
   if (h->pip_columns == 1 || (h->pip_columns < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc)) {
-    if (int r = build_strips(h, b)) return r;
+    if (int r = build_strips(h, b, want_sky)) return r;
+  }
+  if (want_sky && !b.use_sky) {
+    RJ_HIP(h, hipMemsetAsync(b.sky, 0, ((size_t) kSkyBuckets + 1) * 4, h->stream));
+    RJ_HIP(h, launch_build_sky(h->stream, b.box0, b.seid, b.n0p, b.sky));
+    b.use_sky = true;
   }
   toc(h, RJ_T_BUILD);
   RJ_HIP(h, hipStreamSynchronize(h->stream));

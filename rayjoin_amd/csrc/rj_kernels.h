@@ -131,7 +131,7 @@ hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* 
                               void* temp, size_t& temp_bytes, uint32_t* flag);
 hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* seid, const int32_t* sface, const uint32_t* cnt,
                              const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint32_t* key, uint32_t* eslot, uint32_t* key_tmp,
-                             uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, void* temp,
+                             uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, uint32_t* sky, void* temp,
                              size_t& temp_bytes);
 hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, int cus);
 // Polyline runs of a map, cut on the device (rj_stitch.hip): pieces and runs into caller-owned arrays sized by
@@ -148,9 +148,10 @@ hipError_t launch_pack_runs(hipStream_t st, const uint32_t* order, const uint32_
                             unsigned long long* total_out);
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
-                               const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* leaf_first, uint64_t nblocks,
+                               const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* run_len, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, uint32_t* sky);
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ);
+hipError_t launch_build_sky(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* sky);
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
                                uint64_t n_parent_alloc);

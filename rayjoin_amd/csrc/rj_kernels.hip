@@ -336,13 +336,13 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       const uint32_t* __restrict__ piece_begin,
                                                       const uint32_t* __restrict__ piece_len,
                                                       const uint32_t* __restrict__ run_first,
+                                                      const uint32_t* __restrict__ run_len,
                                                       const uint32_t* __restrict__ leaf_first,
                                                       uint64_t nblocks, uint64_t n_parent_alloc,
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
                                                       int32_t* __restrict__ pmx1, uint2* __restrict__ xtab,
-                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ,
-                                                      uint32_t* __restrict__ sky) {
+                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ) {
   __shared__ int32_t sx1[4][64];
   __shared__ uint4 hist[4][64];  // 256 x-bucket counters per wave
   const int lane = lane_id();
@@ -364,18 +364,35 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     // that follow each other in the sorted order (`order` sorts the runs, leaf_first[blk] is the block's first).
     bool valid = i < ne;
     if (piece_begin) {
-      valid = false;
-      uint32_t acc = 0;
-      for (uint32_t j = leaf_first[blk]; j < leaf_first[blk + 1]; j++) {  // the leaf's runs (k_pack_runs): one, or a few short ones
-        const uint32_t r = order[j];
-        for (uint32_t p = run_first[r]; p < run_first[r + 1]; p++) {  // (wave-uniform bounds and loads; a handful of pieces)
-          const uint32_t len = piece_len[p];
-          if (!valid && (uint32_t) lane < acc + len) {
-            valid = true;
-            id = piece_begin[p] + ((uint32_t) lane - acc);
-          }
-          acc += len;
-        }
+      // The leaf's runs (k_pack_runs): one, or a few short ones -- at most 64, a run has an edge.  Lane l fetches run l
+      // (its place in the sorted order, its length, its first piece), a prefix sum places the runs in the block, and the
+      // lane of slot s then walks the pieces of ITS run only: four dependent loads deep whatever the number of runs.
+      // (Round 4's form walked runs and pieces one after the other with wave-uniform loads: a dozen dependent round
+      //  trips per block on a map of ten-edge rings -- 2.5 of the 9.2 ms of the lake-shaped map's first index build.)
+      const uint32_t j0 = leaf_first[blk], nr = leaf_first[blk + 1] - j0;
+      uint32_t rlen = 0, rf = 0;
+      if ((uint32_t) lane < nr) {
+        const uint32_t r = order[j0 + (uint32_t) lane];
+        rlen = run_len[r];
+        rf = run_first[r];
+      }
+      uint32_t inc = rlen;  // where run `lane` ends in the block
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t) __shfl_up((int) inc, d, 64);
+        if (lane >= d) inc += t;
+      }
+      uint32_t k = 0;  // the run slot `lane` lies in: how many runs end at or before it
+      for (uint32_t q = 0; q < nr; q++) k += (uint32_t) bcast((int32_t) inc, (int) q) <= (uint32_t) lane ? 1u : 0u;
+      valid = k < nr;
+      const uint32_t kk = valid ? k : 0u;
+      const uint32_t run_end = (uint32_t) __shfl((int) inc, (int) kk, 64), run_n = (uint32_t) __shfl((int) rlen, (int) kk, 64);
+      uint32_t p = (uint32_t) __shfl((int) rf, (int) kk, 64);
+      if (valid) {
+        uint32_t off = (uint32_t) lane - (run_end - run_n);
+        uint32_t len = piece_len[p];
+        while (off >= len) { off -= len; p++; len = piece_len[p]; }  // (a handful of pieces)
+        id = piece_begin[p] + off;
       }
     } else if (valid) {
       id = __builtin_nontemporal_load(&order[i]);
@@ -390,16 +407,6 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
       b.y1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
     }
     mark_occupancy_wave(b, valid, occ, lane);
-    if (valid && sky) {  // the skyline (maps of isolated rings only): every x-bucket the segment's box touches is at least this high
-      const int k0 = b.x0 >> kSkyShift, k1 = b.x1 >> kSkyShift;
-      const uint32_t top = (uint32_t) b.y1 + 1u;
-      if (k1 - k0 >= kSkyMaxSpan) {
-        sky[kSkyBuckets] = 1u;
-      } else {
-        for (int k = k0; k <= k1; k++)  // (neighbours in a leaf raise the same buckets: look before paying an atomic)
-          if (__hip_atomic_load(&sky[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < top) atomicMax(&sky[k], top);
-      }
-    }
     int rank = 0;
     for (int k = 0; k < 64; k++) {
       const int32_t xk = bcast(b.x0, k);
@@ -458,6 +465,26 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
       }
       xtab[blk * 64 + lane] = make_uint2(packed[0], packed[1]);
       wave_lds_fence();
+    }
+  }
+}
+
+// The skyline (maps of isolated rings that have no column index): every x-bucket a segment's box touches is at least as
+// high as the box.  A pass of its own over the built leaves' boxes -- inside k_build_leaves it was 0.96 of that kernel's
+// 2.19 ms on the lake-shaped map (an L2 look and sometimes an atomic per segment and bucket), paid by every build of a
+// ring map although the default PIP path of such a map, the column index, never reads the table.
+__global__ __launch_bounds__(256) void k_build_sky(const QBox* __restrict__ box0, const uint32_t* __restrict__ seid, uint64_t n0p,
+                                                   uint32_t* __restrict__ sky) {
+  for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n0p; i += (uint64_t) gridDim.x * blockDim.x) {
+    if (seid[i] == 0xFFFFFFFFu) continue;
+    const QBox b = box0[i];
+    const int k0 = b.x0 >> kSkyShift, k1 = b.x1 >> kSkyShift;
+    const uint32_t top = (uint32_t) b.y1 + 1u;
+    if (k1 - k0 >= kSkyMaxSpan) {
+      sky[kSkyBuckets] = 1u;
+    } else {
+      for (int k = k0; k <= k1; k++)  // (neighbours in a leaf raise the same buckets: look before paying an atomic)
+        if (__hip_atomic_load(&sky[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < top) atomicMax(&sky[k], top);
     }
   }
 }
@@ -2479,11 +2506,16 @@ hipError_t launch_pack_runs(hipStream_t st, const uint32_t* order, const uint32_
 
 hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* order, const uint32_t* edge_chain,
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
-                               const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* leaf_first, uint64_t nblocks,
+                               const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* run_len, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, uint32_t* sky) {
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, piece_begin, piece_len, run_first, leaf_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ, sky);
+                     left, right, ne, piece_begin, piece_len, run_first, run_len, leaf_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_sky(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* sky) {
+  hipLaunchKernelGGL(k_build_sky, dim3(grid_for(n0p, 256, 8192)), dim3(256), 0, st, box0, seid, n0p, sky);
   return hipGetLastError();
 }
 

@@ -51,17 +51,16 @@ constexpr int kStripBandShift = 15, kStripBandBits = 31 - kStripBandShift;
 __device__ __forceinline__ uint32_t strip_key(uint32_t strip, int32_t y0) { return (strip << kStripBandBits) | ((uint32_t) y0 >> kStripBandShift); }
 __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box0, const uint32_t* __restrict__ cnt,
                                                     const uint32_t* __restrict__ offs, uint64_t n0p, int shift, uint32_t* __restrict__ key,
-                                                    uint32_t* __restrict__ slot, uint32_t* __restrict__ tall) {
+                                                    uint32_t* __restrict__ slot) {
   RJ_GRID_STRIDE(i, n0p) {
     const uint32_t c = cnt[i];
     if (!c) continue;
     const QBox b = box0[i];
-    const uint32_t s0 = (uint32_t) (b.x0 >> shift), h = (uint32_t) (b.y1 - b.y0);
+    const uint32_t s0 = (uint32_t) (b.x0 >> shift);
     const uint32_t o = offs[i];
     for (uint32_t k = 0; k < c; k++) {
       key[o + k] = strip_key(s0 + k, b.y0);
       slot[o + k] = (uint32_t) i;
-      if (__hip_atomic_load(&tall[s0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < h) atomicMax(&tall[s0 + k], h);
     }
   }
 }
@@ -73,17 +72,66 @@ __global__ __launch_bounds__(256) void k_strip_emit(const QBox* __restrict__ box
 __device__ __forceinline__ uint32_t strip_bucket(uint32_t key) {
   return ((key >> kStripBandBits) << kStripYBits) | ((key & ((1u << kStripBandBits) - 1u)) >> (kStripYShift - kStripBandShift));
 }
+// ... and every strip's tallest box (tall[s]: what a point's scan must start below itself by) and, where asked for, the
+// map's SKYLINE (rj_device.h kSkyShift: per 2^13-quanta bucket 1 + the highest y1 of any box over it), from data this
+// pass holds anyway.  The entries of a strip are consecutive: the maxima are taken over each wave's runs of equal strip
+// first -- one atomicMax per run and bucket, not per entry.  (Round 4 raised `tall` from k_strip_emit, a look
+// at the L2 per entry, and the skyline from k_build_leaves, one per segment and bucket: 0.96 ms of the lake-shaped
+// map's 9.2 ms first build.)
 __global__ __launch_bounds__(256) void k_strip_finish(const uint32_t* __restrict__ key, const uint32_t* __restrict__ slot, uint64_t n,
                                                       const QBox* __restrict__ box0, const uint32_t* __restrict__ seid,
                                                       const int32_t* __restrict__ sface, QBox* __restrict__ ebox,
-                                                      uint4* __restrict__ einfo, uint32_t* __restrict__ ytab, uint32_t strips) {
-  RJ_GRID_STRIDE(j, n) {
-    const uint32_t sl = slot[j];
-    ebox[j] = box0[sl];
-    einfo[j] = make_uint4(sl, seid[sl], (uint32_t) sface[sl], 0u);
-    const uint32_t g = strip_bucket(key[j]);
-    if (j == 0 || strip_bucket(key[j - 1]) != g) ytab[g] = (uint32_t) j;
-    if (j == n - 1) ytab[strips << kStripYBits] = (uint32_t) n;
+                                                      uint4* __restrict__ einfo, uint32_t* __restrict__ ytab, uint32_t strips,
+                                                      uint32_t* __restrict__ tall, uint32_t* __restrict__ sky, int shift) {
+  const int lane = (int) (threadIdx.x & 63);
+  const int nsub = 1 << (shift - kSkyShift);  // skyline buckets per strip: 4, 8 or 16
+  for (uint64_t base = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x - (uint64_t) lane; base < n; base += (uint64_t) gridDim.x * blockDim.x) {
+    const uint64_t j = base + (uint64_t) lane;
+    uint32_t strip = 0xFFFFFFFFu, hgt = 0, tp = 0;
+    int k0 = 0, k1 = -1;  // the skyline buckets of the strip this entry's box lies over
+    if (j < n) {
+      const uint32_t sl = slot[j];
+      const QBox b = box0[sl];
+      ebox[j] = b;
+      einfo[j] = make_uint4(sl, seid[sl], (uint32_t) sface[sl], 0u);
+      const uint32_t kj = key[j];
+      const uint32_t g = strip_bucket(kj);
+      if (j == 0 || strip_bucket(key[j - 1]) != g) ytab[g] = (uint32_t) j;
+      if (j == n - 1) ytab[strips << kStripYBits] = (uint32_t) n;
+      strip = kj >> kStripBandBits;
+      hgt = (uint32_t) (b.y1 - b.y0);
+      tp = (uint32_t) b.y1 + 1u;
+      const int first = (int) (strip << (shift - kSkyShift));
+      k0 = (b.x0 >> kSkyShift) - first; k1 = (b.x1 >> kSkyShift) - first;
+      k0 = k0 < 0 ? 0 : k0; k1 = k1 >= nsub ? nsub - 1 : k1;
+    }
+    const uint32_t before = (uint32_t) __shfl_up((int) strip, 1, 64);
+    const bool head = j < n && (lane == 0 || before != strip);
+    bool same[6];  // lane + 2^i holds an entry of the same strip
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const uint32_t os = (uint32_t) __shfl_down((int) strip, 1 << i, 64);  // (read by ALL lanes: not behind the && below)
+      same[i] = lane + (1 << i) < 64 && os == strip;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const uint32_t oh = (uint32_t) __shfl_down((int) hgt, 1 << i, 64);
+      if (same[i]) hgt = oh > hgt ? oh : hgt;
+    }
+    if (head) atomicMax(&tall[strip], hgt);
+    if (sky) {
+      for (int k = 0; k < nsub; k++) {
+        uint32_t v = (k0 <= k && k <= k1) ? tp : 0u;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const uint32_t ov = (uint32_t) __shfl_down((int) v, 1 << i, 64);
+          if (same[i]) v = ov > v ? ov : v;
+        }
+        // (no look before the atomic here: a wave would wait for nsub dependent round trips to the L2 per 64 entries --
+        //  1.8 ms of the lake-shaped map's build -- where an atomic without a return value is not waited for at all)
+        if (head && v) atomicMax(&sky[(strip << (shift - kSkyShift)) + (uint32_t) k], v);
+      }
+    }
   }
 }
 
@@ -104,7 +152,15 @@ __global__ __launch_bounds__(256) void k_strip_width(const QBox* __restrict__ bo
     if (seid[k] != 0xFFFFFFFFu) { const QBox b = box0[k]; w += (unsigned long long) (b.x1 - b.x0); c++; }
   }
   for (int o = 32; o > 0; o >>= 1) { w += __shfl_down(w, o, 64); c += __shfl_down(c, o, 64); }
-  if ((threadIdx.x & 63) == 0 && c) { atomicAdd(&out[0], w); atomicAdd(&out[1], c); }
+  // (one pair of atomics per BLOCK, on a grid of a block per CU or two: 16 k atomics on one address -- a pair per wave of
+  //  2048 blocks -- were 0.19 of the kernel's 0.21 ms)
+  __shared__ unsigned long long part[2][4];
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = w; part[1][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long ws = part[0][0] + part[0][1] + part[0][2] + part[0][3], cs = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+    if (cs) { atomicAdd(&out[0], ws); atomicAdd(&out[1], cs); }
+  }
 }
 
 // PTS query points per lane: a wave takes PTS x 64 consecutive positions (point set p = positions 64 p + lane of the
@@ -353,7 +409,7 @@ hipError_t warm_strip_kernels(hipStream_t st) {
 hipError_t launch_strip_width(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, unsigned long long* out2) {
   hipError_t e = hipMemsetAsync(out2, 0, 16, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_width, dim3(blocks_for(n0p / 64 + 1, 256, 2048)), dim3(256), 0, st, box0, seid, n0p, out2);
+  hipLaunchKernelGGL(k_strip_width, dim3(blocks_for(n0p / 64 + 1, 256, 512)), dim3(256), 0, st, box0, seid, n0p, out2);
   return hipGetLastError();
 }
 hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, int shift, uint32_t* cnt, uint32_t* offs,
@@ -369,7 +425,7 @@ hipError_t launch_strip_count(hipStream_t st, const QBox* box0, const uint32_t* 
 // table; key / eslot / key_tmp / slot_tmp: temporaries of `entries` elements; tall[strips] (temporary) zeroed here
 hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* seid, const int32_t* sface, const uint32_t* cnt,
                              const uint32_t* offs, uint64_t n0p, int shift, uint64_t entries, uint32_t* key, uint32_t* eslot, uint32_t* key_tmp,
-                             uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, void* temp,
+                             uint32_t* slot_tmp, uint32_t* tall, uint32_t* ytab, QBox* ebox, uint4* einfo, uint2* tall_end, uint32_t* sky, void* temp,
                              size_t& temp_bytes) {
   const unsigned bits = (unsigned) kStripBandBits + (31 - shift);  // (<= 32: strips of 2^15 quanta or wider)
   const uint32_t strips = strip_count(shift);
@@ -386,11 +442,11 @@ hipError_t launch_strip_fill(hipStream_t st, const QBox* box0, const uint32_t* s
   }
   hipError_t e = hipMemsetAsync(tall, 0, (size_t) strips * 4, st);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_emit, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, cnt, offs, n0p, shift, key_tmp, slot_tmp, tall);
+  hipLaunchKernelGGL(k_strip_emit, dim3(blocks_for(n0p)), dim3(256), 0, st, box0, cnt, offs, n0p, shift, key_tmp, slot_tmp);
   if ((e = rocprim::radix_sort_pairs(temp, temp_bytes, key_tmp, key, slot_tmp, eslot, (size_t) entries, 0, bits, st)) != hipSuccess) return e;
   const size_t nt = ((size_t) strips << kStripYBits) + 1;
   if ((e = hipMemsetAsync(ytab, 0xFF, nt * 4, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_strip_finish, dim3(blocks_for(entries)), dim3(256), 0, st, key, eslot, entries, box0, seid, sface, ebox, einfo, ytab, strips);
+  hipLaunchKernelGGL(k_strip_finish, dim3(blocks_for(entries)), dim3(256), 0, st, key, eslot, entries, box0, seid, sface, ebox, einfo, ytab, strips, tall, sky, shift);
   // suffix minimum, in place (the sort's temporary storage is free again and larger than a scan's)
   size_t need = 0;
   auto rb = rocprim::make_reverse_iterator(ytab + nt);

@@ -46,6 +46,9 @@ def test_columns_equal_the_walk_and_the_oracle(oracle, what):
                 assert used == (1 if columns == 1 else 0 if columns == 0 else used)
                 if columns == -1 and base == 0:
                     assert used == (0 if what == "lattice" else 1), what   # built where most chains are closed rings
+                if what == "rings" and base == 0:
+                    # the skyline table: filled by the column index's own pass or, without one, from the leaves' boxes
+                    assert h.get_option("skyline_used0") == 1, (what, columns)
                 e, f = _pip(h, base, None, q.n_points, closest, faces)
                 assert h.get_option("pip_last_columns") == used
                 assert np.array_equal(e, want), (what, base, columns)
