@@ -172,15 +172,24 @@ __global__ __launch_bounds__(256) void k_strip_width(const QBox* __restrict__ bo
 //  and 1.5-1.7x SLOWER: first pass alone 2.33 -> 3.98 / 3.59 ms at U = 1 / 4 on the lake-shaped pair, 1.96 -> 3.05 / 2.70
 //  lakes x parks.  A lane that is done must stop reading, and it can only do so behind a branch: the pass is bound by
 //  the number of lane-reads the texture path serves, not by how long a wave waits for them.)
+// (Round 5, tried and dropped: every XCD on one contiguous eighth of the query set instead of the plain stride over the
+//  grid, so that neighbouring groups meet in ONE L2 -- lake-shaped pair 1.79 -> 2.04 ms in the step, lakes x parks 1.58 ->
+//  1.59: the eighths are unequal and nothing was being fetched eight times.)
 // (entries a point reads on its own before the wave takes its scan over.  First pass, ms, at 8 / 12 / 16 / 24 / 32 / 48 / 64 /
 //  never: lake-shaped base x lattice vertices 2.70 / 2.32 / 2.14 / 1.92 / 1.80 / 1.86 / 1.95 / 2.13; lakes x parks 2.40 / 1.87 /
 //  1.68 / 1.61 / 1.62 / 1.70 / 1.77 / 1.94; gaussian polygons 1.27 / 0.93 / 0.75 / 0.62 / 0.59 / 0.58 / 0.59 / 0.58: a
 //  cooperative trip costs about three solo ones, so it pays for the 3 % of the points that need more than 32 entries --
-//  which nearly every wave has -- and not for the 10 % beyond 16)
+//  which nearly every wave has -- and not for the 10 % beyond 16.  With two entries per solo trip and the records looked
+//  up at the hand-over, at 16 / 24 / 32 / 48 / 64: 1.84 / 1.65 / 1.51 / 1.45 / 1.50; 1.40 / 1.30 / 1.28 / 1.30 / 1.34;
+//  0.59 / 0.46 / 0.44 / 0.43 / 0.43: 48)
 #ifndef RJ_STRIP_SOLO
-#define RJ_STRIP_SOLO 32
+#define RJ_STRIP_SOLO 48
 #endif
 constexpr int kStripSolo = RJ_STRIP_SOLO;
+#ifndef RJ_STRIP_PER_TRIP
+#define RJ_STRIP_PER_TRIP 2
+#endif
+constexpr int kStripPerTrip = RJ_STRIP_PER_TRIP;  // entries of a point read per solo trip
 template <int PTS, bool STATS = false>
 __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
   __shared__ uint32_t cand_all[4][PTS * kWalkList * 64];
@@ -200,7 +209,6 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     bool valid[PTS];
     uint32_t ip[PTS], j[PTS], jend[PTS], cand_base[PTS], cand_at[PTS];
     int32_t qx[PTS], qy[PTS], qym1[PTS], qbest[PTS], sure_y0[PTS];
-    uint32_t sure_eid[PTS], sure_face[PTS];  // edge and face of the one certain hit a list holds (valid where sure_y0 is)
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
       const uint64_t ipos = g * per_group + (uint64_t) p * 64 + lane;
@@ -218,7 +226,6 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       cand_base[p] = (uint32_t) lane + (uint32_t) p * (kWalkList * 64);
       cand_at[p] = cand_base[p];
       sure_y0[p] = INT32_MIN;
-      sure_eid[p] = 0xFFFFFFFFu; sure_face[p] = 0;
       j[p] = jend[p] = 0;
     }
     // the strip's entries from the height bucket of the lowest y0 that can still reach up to the point
@@ -226,6 +233,10 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     // (A sentinel entry behind every strip instead of reading where the strip ends was tried: a lane that is done
     //  cannot stop reading without a branch around the loads, and the pass is bound by the number of random reads:
     //  2.61 / 4.58 ms against 2.42 / 4.01.)
+    // (Round 5, tried and dropped: the skyline's word, the strip's {tallest box, end} and the table's entries for the point's
+    //  own bucket and the one below requested at once, without the branches -- one round trip instead of three per group,
+    //  and 17-27 % SLOWER (1.51 -> 1.77, 1.25 -> 1.59, 0.44 -> 0.49 ms): the reads a miss and a position past the end do
+    //  not make, and the second table word, cost this pass more than the two round trips.)
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
       if (valid[p] && ray_has_sky(sky, qx[p], qy[p])) {  // (above the map's skyline: a certain miss)
@@ -246,38 +257,46 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
     // wave went on until its slowest lane was done: ~60 trips for points that need 7.5 entries on average -- is finished
     // by the whole wave, 64 consecutive entries per trip (below).
     const int solo = A.walk_stack > 0 ? A.walk_stack : kStripSolo;  // ("walk_stack", a debug knob: experiments with the hand-over point)
-    for (int trip = 0; trip < solo; trip++) {
+    for (int trip = 0; trip < solo; trip += kStripPerTrip) {
       bool more = false;
-      QBox b[PTS];
+      QBox bb[PTS][kStripPerTrip];
       if (STATS) st_iter++;
+      // (the reads of all points first: they are what the lane waits for.  kStripPerTrip consecutive entries of a point per
+      //  trip: the second is in the first one's line seven times out of eight, and the wave's trips -- the round trips to
+      //  memory its groups are made of -- halve)
 #pragma unroll
-      for (int p = 0; p < PTS; p++)   // (the reads of all points first: they are what the lane waits for)
-        if (j[p] < jend[p]) b[p] = S.ebox[j[p]];
+      for (int p = 0; p < PTS; p++)
+#pragma unroll
+        for (int u = 0; u < kStripPerTrip; u++)
+          if (j[p] + (uint32_t) u < jend[p]) bb[p][u] = S.ebox[j[p] + (uint32_t) u];
 #pragma unroll
       for (int p = 0; p < PTS; p++) {
+#pragma unroll
+       for (int u = 0; u < kStripPerTrip; u++) {
         if (j[p] >= jend[p]) continue;
-        if (STATS) { st_len[p]++; st_below[p] += b[p].y1 < qym1[p] ? 1u : 0u; }
+        const QBox be = bb[p][u];
+        if (STATS) { st_len[p]++; st_below[p] += be.y1 < qym1[p] ? 1u : 0u; }
         // (the entries ascend by BAND of y0, 2^15 quanta: inside a band their order is the build's)
-        if ((b[p].y0 >> kStripBandShift) > (qbest[p] >> kStripBandShift)) { j[p] = jend[p]; continue; }  // everything further starts above the bound
-        if (((qx[p] - b[p].x0) | (b[p].x1 - qx[p]) | (b[p].y1 - qym1[p]) | (qbest[p] - b[p].y0)) >= 0) {
+        if ((be.y0 >> kStripBandShift) > (qbest[p] >> kStripBandShift)) { j[p] = jend[p]; continue; }  // everything further starts above the bound
+        if (((qx[p] - be.x0) | (be.x1 - qx[p]) | (be.y1 - qym1[p]) | (qbest[p] - be.y0)) >= 0) {
           // k_pip_walk's bookkeeping: a certain hit (strictly inside in x, strictly above) bounds the answer; one that
           // ends below the start of the one certain hit held so far replaces it
-          const uint4 inf = S.einfo[j[p]];  // {slot, edge id, face id}: one 16-byte read
-          const uint32_t slot = inf.x;
-          const bool certain = b[p].x0 < qx[p] && qx[p] < b[p].x1 && b[p].y0 > qy[p];
-          const bool replace = certain && b[p].y1 < sure_y0[p];
+          // (the list takes the ENTRY's index: what the entry stands for -- slot, edge id, face id -- is looked up at the
+          //  hand-over, once per settled point and list slot and all at once.  Read here, inside the scan, every candidate
+          //  put a memory round trip into its wave's trip: 18 % of the pass, measured with the read left out)
+          const bool certain = be.x0 < qx[p] && qx[p] < be.x1 && be.y0 > qy[p];
+          const bool replace = certain && be.y1 < sure_y0[p];
           const bool first = cand_at[p] == cand_base[p];
           const bool over = !replace && cand_at[p] == cand_base[p] + kWalkList * 64;
-          cand[(replace || over) ? cand_base[p] : cand_at[p]] = slot;
-          sure_y0[p] = (replace || (first && certain)) ? b[p].y0 : INT32_MIN;
-          sure_eid[p] = (replace || (first && certain)) ? inf.y : sure_eid[p];
-          sure_face[p] = (replace || (first && certain)) ? inf.z : sure_face[p];
+          cand[(replace || over) ? cand_base[p] : cand_at[p]] = j[p];
+          sure_y0[p] = (replace || (first && certain)) ? be.y0 : INT32_MIN;
           cand_at[p] += replace ? 0u : 64u;
-          const int32_t top = certain ? b[p].y1 + 1 : 0x7FFFFFFF;
+          const int32_t top = certain ? be.y1 + 1 : 0x7FFFFFFF;
           qbest[p] = over ? -1 : (top < qbest[p] ? top : qbest[p]);
         }
         j[p]++;
-        more = more || j[p] < jend[p];
+       }
+       more = more || j[p] < jend[p];
       }
       if (!__ballot(more)) break;
     }
@@ -298,7 +317,6 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
         const uint32_t ojend = (uint32_t) bcast((int32_t) jend[p], o);
         const uint32_t obase = (uint32_t) o + (uint32_t) p * (kWalkList * 64);
         uint32_t oat = (uint32_t) bcast((int32_t) cand_at[p], o);
-        uint32_t oeid = (uint32_t) bcast((int32_t) sure_eid[p], o), oface = (uint32_t) bcast((int32_t) sure_face[p], o);
         bool stop = false;
         while (!stop && oj < ojend) {
           if (STATS) st_coop++;
@@ -325,23 +343,17 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
               oqbest = -1;
               stop = true;
             } else {
-              uint4 inf = make_uint4(0, 0, 0, 0);
-              if (is_cand) {
-                inf = S.einfo[idx];
-                cand[oat + 64u * (uint32_t) rank_below(cm)] = inf.x;
-              }
+              if (is_cand) cand[oat + 64u * (uint32_t) rank_below(cm)] = idx;
               const int c0 = __builtin_ctzll(cm);
               const bool settles = fill == 0 && nc == 1 && ((__ballot(certain) >> c0) & 1);
               osure = settles ? bcast(e.y0, c0) : INT32_MIN;
-              oeid = settles ? (uint32_t) bcast((int32_t) inf.y, c0) : oeid;
-              oface = settles ? (uint32_t) bcast((int32_t) inf.z, c0) : oface;
               oat += 64u * nc;
             }
           }
           oj += 64;
         }
         if (lane == o) {
-          qbest[p] = oqbest; sure_y0[p] = osure; cand_at[p] = oat; sure_eid[p] = oeid; sure_face[p] = oface;
+          qbest[p] = oqbest; sure_y0[p] = osure; cand_at[p] = oat;
           j[p] = jend[p];
         }
         wave_lds_fence();
@@ -362,25 +374,40 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
         atomicAdd(&A.stats[5 + bin], 1ull);
       }
     }
-    // hand-over, per point set: exactly k_pip_walk's
+    // hand-over, per point set: exactly k_pip_walk's.  The lists hold entry indices: a settled point reads its one entry's
+    // record {slot, edge id, face id}, a listed point the slots of its entries -- every read of the group requested before
+    // the first is used.
+    bool done[PTS];
+    uint4 sure_inf[PTS];
+    uint32_t lslot[PTS][kWalkList];
 #pragma unroll
     for (int p = 0; p < PTS; p++) {
-      const bool done = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
-      if (done) {
-        // (the hit's edge and face ids came with the slot its candidate was read from: no further read)
-        const bool hit = cand_at[p] != cand_base[p];
-        __builtin_nontemporal_store(hit ? sure_eid[p] : 0xFFFFFFFFu, A.closest + ip[p]);
-        if (A.face) __builtin_nontemporal_store(hit ? (int32_t) sure_face[p] : 0, A.face + ip[p]);
+      done[p] = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
+      const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
+      sure_inf[p] = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
+      if (done[p] && fill) sure_inf[p] = S.einfo[cand[cand_base[p]]];
+      const bool listed = valid[p] && !done[p] && fill <= (uint32_t) kWalkList;
+#pragma unroll
+      for (int k = 0; k < kWalkList; k++) {
+        lslot[p][k] = 0xFFFFFFFFu;
+        if (listed && (uint32_t) k < fill) lslot[p][k] = S.einfo[cand[cand_base[p] + 64 * k]].x;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < PTS; p++) {
+      if (done[p]) {
+        __builtin_nontemporal_store(sure_inf[p].y, A.closest + ip[p]);
+        if (A.face) __builtin_nontemporal_store((int32_t) sure_inf[p].z, A.face + ip[p]);
       }
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
-      const bool listed = valid[p] && !done && fill <= (uint32_t) kWalkList;
-      const bool rest = valid[p] && !done && !listed;
+      const bool listed = valid[p] && !done[p] && fill <= (uint32_t) kWalkList;
+      const bool rest = valid[p] && !done[p] && !listed;
       const uint64_t lm = __ballot(listed);
       const uint64_t g64 = g * PTS + p;  // the 64-position group this set is
       if (listed) {
         const uint64_t rec = g64 * 64 + rank_below(lm);  // (records side by side at the head of the group's region: k_pip_walk)
 #pragma unroll
-        for (int k = 0; k < kWalkList; k++) A.todo[rec * kWalkList + k] = (uint32_t) k < fill ? cand[cand_base[p] + 64 * k] : 0xFFFFFFFFu;
+        for (int k = 0; k < kWalkList; k++) A.todo[rec * kWalkList + k] = lslot[p][k];
       }
       if (lane == 0 && g64 * 64 < A.n) A.todo_mask[g64] = lm;
       const uint64_t rm = __ballot(rest);
