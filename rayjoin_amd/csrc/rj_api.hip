@@ -48,6 +48,8 @@ struct BvhState {
   bool built = false;
   int leaf_order = 0;  // how this index's leaves were formed (0 Hilbert neighbours, 1 chain runs)
   uint64_t n0 = 0, n0p = 0;
+  char* pool = nullptr;  // ONE device block for the arrays below and the levels where they are small (eleven hipMallocs were 0.2 ms of a 1.5 ms
+                         // first build); nullptr: an allocation each (large maps: ONE hipMalloc of 4.6 GB took 120 ms where the eleven take 1)
   Seg* sseg = nullptr;
   uint32_t* seid = nullptr;
   int32_t* sface = nullptr;
@@ -254,7 +256,7 @@ struct rj_handle_s {
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
   int group_lanes = 0;       // queries per wave: 0 = automatic (64 unless the query set is small)
   uint64_t last_stats[16] = {0};
-  // grow-only arena for the overlay pass (carved per call, no per-call hipMalloc/hipFree)
+  // grow-only arena for the overlay pass and for the run cutting of a first index build (carved per call, no per-call hipMalloc/hipFree)
   char* arena = nullptr;
   size_t arena_bytes = 0;
   ncclComm_t comm = nullptr;
@@ -348,9 +350,13 @@ void free_grid(GridState& g) {
 }
 
 void free_bvh(BvhState& b) {
-  (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
+  if (b.pool) {
+    (void) hipFree(b.pool);  // (sseg ... sky and the levels are carved out of it)
+  } else {
+    (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
+    for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
+  }
   (void) hipFree(b.strip_ytab); (void) hipFree(b.strip_info); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_box);
-  for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   b = BvhState();
 }
 
@@ -1172,7 +1178,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     hipError_t e = hipSuccess;
     uint64_t nruns_cut = 0, npieces_cut = 0;
     if (!rc) e = stitch_runs_device(h->stream, mm.pts, mm.edge_begin, mm.nc, mm.ne, cap_edges, mm.piece_begin, mm.piece_len, mm.run_first,
-                                    &nruns_cut, &npieces_cut, h->stitch_stats);
+                                    &nruns_cut, &npieces_cut, h->stitch_stats, &h->arena, &h->arena_bytes);
     if (rc || e != hipSuccess) {  // no half-cut map: a retried build starts over
       (void) hipFree(mm.piece_begin); (void) hipFree(mm.piece_len); (void) hipFree(mm.run_first);
       mm.piece_begin = mm.piece_len = mm.run_first = nullptr;
@@ -1255,17 +1261,37 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   if (b.nlvl[top] > 64) return fail(h, RJ_E_INVALID, "too many segments for %d levels", kMaxLevels);
   b.top = top;
   if (!reuse) {
-    int r = 0;
-    if (!r) r = dev_alloc(h, &b.sseg, b.n0p);
-    if (!r) r = dev_alloc(h, &b.seid, b.n0p);
-    if (!r) r = dev_alloc(h, &b.sface, b.n0p);
-    if (!r) r = dev_alloc(h, &b.box0, b.n0p);
-    if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
-    if (!r) r = dev_alloc(h, &b.xtab, b.n0p);
-    if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
-    if (!r) r = dev_alloc(h, &b.sky, (uint64_t) kSkyBuckets + 1);  // (1 MiB: allocated with the index, filled when wanted)
-    for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l] + b.alloc[l] / 2);  // 16 B box + 8 B order word per node
-    if (r) { free_bvh(b); return r; }
+    // one block, carved (sizes first, then the pointers); every array starts on a 256-byte boundary
+    size_t used = 0;
+    auto take = [&](size_t bytes) { const size_t at = used; used = (used + bytes + 255) & ~(size_t) 255; return at; };
+    const size_t o_sseg = take(sizeof(Seg) * b.n0p), o_seid = take(4 * b.n0p), o_sface = take(4 * b.n0p), o_box0 = take(sizeof(QBox) * b.n0p),
+                 o_pmx1 = take(4 * b.n0p), o_xtab = take(sizeof(uint2) * b.n0p), o_occ = take(4 * ((size_t) kOccDim * kOccRowWords + 1)),
+                 o_sky = take(4 * ((size_t) kSkyBuckets + 1));  // (the skyline's 1 MiB: allocated with the index, filled when wanted)
+    size_t o_lvl[kMaxLevels] = {0};
+    for (int l = 1; l <= top; l++) o_lvl[l] = take(sizeof(QBox) * (b.alloc[l] + b.alloc[l] / 2));  // 16 B box + 8 B order word per node
+    if (used <= ((size_t) 5 << 29)) {  // (2.5 GiB)
+      const hipError_t pe = hipMalloc((void**) &b.pool, used ? used : 1);
+      if (pe != hipSuccess) {
+        free_bvh(b);
+        return fail(h, pe == hipErrorOutOfMemory ? RJ_E_NOMEM : RJ_E_HIP, "rj_build_lbvh: hipMalloc of %zu bytes for the index failed: %s", used, hipGetErrorString(pe));
+      }
+      b.sseg = (Seg*) (b.pool + o_sseg); b.seid = (uint32_t*) (b.pool + o_seid); b.sface = (int32_t*) (b.pool + o_sface);
+      b.box0 = (QBox*) (b.pool + o_box0); b.pmx1 = (int32_t*) (b.pool + o_pmx1); b.xtab = (uint2*) (b.pool + o_xtab);
+      b.occ = (uint32_t*) (b.pool + o_occ); b.sky = (uint32_t*) (b.pool + o_sky);
+      for (int l = 1; l <= top; l++) b.lvl[l] = (QBox*) (b.pool + o_lvl[l]);
+    } else {
+      int r = 0;
+      if (!r) r = dev_alloc(h, &b.sseg, b.n0p);
+      if (!r) r = dev_alloc(h, &b.seid, b.n0p);
+      if (!r) r = dev_alloc(h, &b.sface, b.n0p);
+      if (!r) r = dev_alloc(h, &b.box0, b.n0p);
+      if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
+      if (!r) r = dev_alloc(h, &b.xtab, b.n0p);
+      if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
+      if (!r) r = dev_alloc(h, &b.sky, (uint64_t) kSkyBuckets + 1);
+      for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l] + b.alloc[l] / 2);
+      if (r) { free_bvh(b); return r; }
+    }
   }
   // 1. Morton keys  2. radix sort (key, eid)  (Hilbert leaves; the runs were keyed and sorted above)
   // 3. leaves + occupancy + level 1 in one pass  4. upper levels

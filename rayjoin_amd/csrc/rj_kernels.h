@@ -139,7 +139,8 @@ hipError_t launch_pip_strip(hipStream_t st, const PipArgs& a, int max_blocks, in
 void stitch_output_bounds(uint64_t nc, uint64_t ne, uint32_t cap, uint64_t* max_pieces, uint64_t* max_runs);
 hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t* edge_begin, uint64_t nc, uint64_t ne, uint32_t cap,
                               uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first, uint64_t* nruns, uint64_t* npieces,
-                              uint32_t* stats /* [4] nullable: ranking rounds, incidences on closed loops, rounds of the second ranking, closed chains */);
+                              uint32_t* stats /* [4] nullable: ranking rounds, incidences on closed loops, rounds of the second ranking, closed chains */,
+                              char** scratch, size_t* scratch_bytes /* the caller's grow-only device block: grown here when too small, never freed here */);
 hipError_t launch_run_keys(hipStream_t st, const Seg* seg, const uint32_t* piece_begin, const uint32_t* piece_len, const uint32_t* run_first,
                            uint64_t nruns, MortonKey* keys, uint32_t* vals, uint32_t* run_len, QBox* run_box, uint32_t box_upto);
 uint64_t pack_runs_chunks(uint64_t nruns);

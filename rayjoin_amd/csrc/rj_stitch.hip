@@ -148,7 +148,7 @@ void stitch_output_bounds(uint64_t nc, uint64_t ne, uint32_t cap, uint64_t* max_
 
 hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t* eb, uint64_t nc64, uint64_t ne, uint32_t cap,
                               uint32_t* piece_begin, uint32_t* piece_len, uint32_t* run_first, uint64_t* nruns, uint64_t* npieces,
-                              uint32_t* stats) {
+                              uint32_t* stats, char** scratch, size_t* scratch_bytes) {
   *nruns = *npieces = 0;
   if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
   if (nc64 == 0) return hipMemsetAsync(run_first, 0, 4, st);
@@ -194,7 +194,15 @@ hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t
   };
   carve();
   A.size = A.used;
-  if ((e = hipMalloc((void**) &A.base, A.size)) != hipSuccess) return e;
+  // (the caller's grow-only block: freeing a block of its own cost every first build of a map 0.25 ms -- hipFree waits
+  //  for the device and unmaps -- a sixth of the headline map's)
+  if (*scratch_bytes < A.size) {
+    (void) hipFree(*scratch);
+    *scratch = nullptr; *scratch_bytes = 0;
+    if ((e = hipMalloc((void**) scratch, A.size)) != hipSuccess) return e;
+    *scratch_bytes = A.size;
+  }
+  A.base = *scratch;
   carve();
   Link* links = nullptr;
   Meta hm;
@@ -266,7 +274,6 @@ hipError_t stitch_runs_device(hipStream_t st, const int64_t* pts, const uint32_t
     *npieces = hm.npieces;
   } while (0);
   (void) hipFree(links);
-  (void) hipFree(A.base);
   return e;
 }
 
