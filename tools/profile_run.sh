@@ -28,7 +28,8 @@ tail -c 300 gpurun_out/${TAG}_bench.json || true
 fi
 # Round 5: sections of counter passes beside the headline's full grids (tools/regime_probe.py: the profiler serialises
 # kernels, so a regime is profiled kernel by kernel on that regime's grids).  "shared" = the headline's kernels on the
-# grids of the shared schedule (k_lsi2 on 512 blocks, k_pip_walk2 on 1 536); the ring-shaped pairs on their full grids.
+# grids of the shared schedule (k_lsi2 on 512 blocks, k_pip_walk2 on 1 536); the other pairs of the bench line (ring-shaped
+# and the default run's secondaries) on their full grids.
 cd /tmp
 section() {  # name, regime_probe arguments ...
   local NAME=$1; shift
@@ -37,7 +38,9 @@ section() {  # name, regime_probe arguments ...
   done
   echo "section $NAME done"
 }
-if [[ " ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike} " == *" shared "* ]]; then section shared --lsi-blocks 512 --pip-blocks 1536; fi
-if [[ " ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike} " == *" WaterBodiesLike_BlockGroup "* ]]; then section WaterBodiesLike_BlockGroup --base WaterBodiesLike --query BlockGroup; fi
-if [[ " ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike} " == *" LakesLike_ParksLike "* ]]; then section LakesLike_ParksLike --base LakesLike --query ParksLike; fi
+# (a section named <Base>_<Query> is that pair on its full grids; "shared" as above)
+for S in ${SECTIONS:-shared WaterBodiesLike_BlockGroup LakesLike_ParksLike USCounty_NestedBlockGroup WaterBodies_BlockGroup USCounty_CrossingZipcode}; do
+  if [[ "$S" == "shared" ]]; then section shared --lsi-blocks 512 --pip-blocks 1536
+  elif [[ "$S" == *_* ]]; then section $S --base ${S%%_*} --query ${S#*_}; fi
+done
 cd $R

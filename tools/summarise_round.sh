@@ -4,7 +4,7 @@
 TAG=${1:?tag}; G=gpurun_out
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 SEC=""
-for s in shared WaterBodiesLike_BlockGroup LakesLike_ParksLike; do
+for s in shared WaterBodiesLike_BlockGroup LakesLike_ParksLike USCounty_NestedBlockGroup WaterBodies_BlockGroup USCounty_CrossingZipcode; do
   [ -d $G/${TAG}_${s}_fetch ] && SEC="$SEC --section $s $G/${TAG}_${s}_fetch $G/${TAG}_${s}_write $G/${TAG}_${s}_sq1 $G/${TAG}_${s}_sq2"
 done
 python3 tools/pmc_summary.py $TAG $G/${TAG}_fetch $G/${TAG}_write $G/${TAG}_sq1 $G/${TAG}_sq2 $SEC > /dev/null
