@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rayjoin_amd import _capi, maps, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--base", default="WaterBodiesLike"); ap.add_argument("--query", default="BlockGroup"); ap.add_argument("--reps", type=int, default=9)
+ap.add_argument("--columns", type=int, default=None, help="rj_set_option pip_columns before the build (1: force the column index)")
 ap.add_argument("--strip-shift", type=int, default=0, help="debug option strip_shift for the build (0: by the map)")
 ap.add_argument("--query-order", type=int, default=None, help="rj_set_option query_order (2: always through the Morton permutation)")
 a = ap.parse_args()
@@ -15,6 +16,8 @@ ctx = maps.Context([synth.standin(a.base), synth.standin(a.query)]).load()
 b, q = ctx.maps
 h = _capi.Handle(0)
 h.upload_map(0, b.pts, b.row_index, b.left, b.right); h.upload_map(1, q.pts, q.row_index, q.left, q.right)
+if a.columns is not None:
+    h.set_option("pip_columns", a.columns)
 if a.strip_shift:
     h.set_debug_option("strip_shift", a.strip_shift)
 h.build_lbvh(0)
