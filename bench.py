@@ -649,7 +649,9 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             raise SystemExit("bench.py: RCCL counts %s ranks in the communicator, the launcher %d" % (out["ranks"]["rccl_comm_ranks"], world))
         if world > 1:
             out["multi_gpu_note"] = ("no hardware curve exists for N > 1 in this repository's records: this line is whatever node ran it; "
-                                     "single-GPU emulations of a shard (--emulate-shard) are diagnostics, not scaling results")
+                                     "single-GPU emulations of a shard (--emulate-shard) are diagnostics, not scaling results. "
+                                     "The steps of an N > 1 line are the pipelined ones (ms_per_step_synced beside them): the like-for-like figure "
+                                     "of an N = 1 line is its ms_per_step_pipelined, not its ms_per_step")
         out["ms_per_step_median"] = round(step_median_ms, 4)
         out["ms_slowest_step"] = round(step_max_ms, 4)
         if ms_pairs_only is not None:
