@@ -9,12 +9,13 @@ k_pip_exact over the candidate lists it left; its first blocks locate the few po
 Workload (N=1): BASELINE.json configs[1], USCounty (base, 7.1 M segments) |><| BlockGroup
 (query, 28.8 M segments), as synthetic stand-ins of those sizes (the real files are
 not obtainable).  Inputs are resident in HBM before the timed region.  Index build is timed
-separately and reported, never part of `value`.  The default single-GPU run also appends
-`secondary` lines (same schema, fewer steps) for the two harder pairs -- USCounty |><|
-NestedBlockGroup (shared vertices, 11x the intersections) and WaterBodies |><| BlockGroup
-(BASELINE config 5's maps) -- so the best-case lattice is never the only number.
+separately and reported, never part of `value`.  The default single-GPU run also times four
+harder pairs (fewer steps) -- USCounty |><| NestedBlockGroup (shared vertices, 11x the
+intersections), WaterBodies |><| BlockGroup (BASELINE config 5's maps), a lake-shaped base map and a
+query map with the published intersection density -- so the best-case lattice is never the only number.
 
-N>1 (torchrun, one rank per GPU): the query map is sharded by contiguous chain ranges balanced
+N>1 (`python bench.py --gpus N` starts its own N ranks; under a launcher -- torch.distributed.run
+--nproc-per-node N bench.py [--gpus N] -- it is one of them, one rank per GPU): the query map is sharded by contiguous chain ranges balanced
 by edge count, the base map + LBVH are replicated.  The exchanges of a step are the RCCL
 all-gather-v of the intersection queues (count + pairs in one collective on a second stream,
 overlapped with the PIP kernels) and the all-gather of the PIP result queues (closest eids,
@@ -22,7 +23,9 @@ overlapped with the PIP kernels) and the all-gather of the PIP result queues (cl
 complete inside the timed region).  `ms_per_step_pairs_only` times the same steps without the PIP
 gather.  Total work is fixed: "strong" scaling.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0's stdout: the headline, under 6 000 bytes (contract fields, config, flat
+rooflines, cpu_baseline, one short entry per secondary pair).  Each secondary pair's compact line goes
+to stderr before it, the full record (plan, checks, instruction rooflines ...) to the --detail file.
 """
 import argparse
 import gc
@@ -37,6 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_ACHIEVABLE_GBS = 6290.0  # measured streaming rate, same guide ("Chip-level parameters"): what `limiter` prices moved bytes against
 # the harder pairs that ride in the default line: nested maps (shared vertices), the 4-level WaterBodies lattice, and a
 # LAKE-SHAPED base map (2.44 M isolated rings of ~10 edges: the topology the reference's water-body / lake / park
 # inputs have and no lattice has -- short rings sharing leaves, a third of the query vertices with nothing above them)
@@ -49,7 +53,7 @@ SECONDARY = (("USCounty", "NestedBlockGroup"), ("WaterBodies", "BlockGroup"), ("
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="default: the launcher's WORLD_SIZE, or 1")
     ap.add_argument("--steps", type=int, default=5)    # the reference's -repeat=5
     ap.add_argument("--warmup", type=int, default=5)   # the reference's -warmup=5 (four pairs settle the kernel schedule)
     ap.add_argument("--base", default="USCounty")
@@ -66,6 +70,9 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary lines (nested and WaterBodies pairs)")
     ap.add_argument("--emulate-shard", type=int, default=0, metavar="N",
                     help="diagnostic, 1 GPU: time rank 0's shard of an N-way run (no exchange); the line is marked as such")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the FULL record goes (every field of the headline and of each secondary pair, the handle's plan, "
+                         "the checks, the instruction rooflines): stdout carries the compact headline only")
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0, collectives over gloo")
     return ap.parse_args()
@@ -268,7 +275,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         barrier()
         h.set_option("timers", 0)
         t0 = time.perf_counter()
-        n = 0
+        n = b = 0
         for j in range(k):
             b = j % 2
             closest = closest2[b]
@@ -529,6 +536,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
             if traffic.get(kern):
                 # (the counter passes run each kernel alone on its full grid: price the bytes against THAT time)
                 r["traffic_frac"] = round(traffic[kern] / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                # ... and against the time it takes IN the timed steps (beside the other side, on its share of the chip)
+                r["frac_moved_bytes"] = round(traffic[kern] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                 if traffic[kern] < b:
                     r["traffic_note"] = ("moves less than the algorithmic bytes: %s" %
                                          ("a pre-filter built at upload (4-byte cell codes + the base map's occupancy bitmap) skips "
@@ -546,9 +555,18 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                     units = n_p_loc if name == "pip" else n_s_loc
                     r["valu_per_query"] = round(c["SQ_INSTS_VALU"] / units, 2)
                     r["salu_per_query"] = round(c.get("SQ_INSTS_SALU", 0) / units, 2)
-                # the measured limiter: the issue port that is busy most of the time, or the latency of dependent loads
-                r["limiter"] = "valu-issue" if r["valu_busy_frac"] > 0.6 else "dependent-load latency"
-                r["limiter_frac"] = r["valu_busy_frac"]
+                # the measured limiter = the LARGEST of: the bytes moved against the HBM rate a kernel can actually reach
+                # (6.29 TB/s streaming, MI355X_MICROARCH.md), the fraction of the VALU issue slots that are busy, and the
+                # fraction of its wave-cycles the kernel spends waiting (dependent-load latency) -- not a threshold on one of them
+                cands = {"valu-issue": r["valu_busy_frac"]}
+                if c.get("SQ_WAIT_ANY") and c.get("SQ_WAVE_CYCLES"):
+                    r["wait_frac"] = round(c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"], 3)
+                    cands["dependent-load latency"] = r["wait_frac"]
+                if traffic.get(kern):
+                    r["traffic_frac_of_achievable"] = round(traffic[kern] / (alone_ms * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS, 5)
+                    cands["hbm-traffic"] = r["traffic_frac_of_achievable"]
+                r["limiter"] = max(cands, key=cands.get)
+                r["limiter_frac"] = round(min(1.0, cands[r["limiter"]]), 3)
                 if c.get("SQ_INSTS_VALU"):
                     # The roofline these kernels actually sit under: a SIMD issues one VALU wave-instruction per 4 cycles whatever
                     # the occupancy (tools/issue_probe.hip measured 4.2), so the chip's ceiling is SIMDs x clock / 4.
@@ -665,6 +683,88 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     return out
 
 
+# ---- what is printed ---------------------------------------------------------------------------------------------------------
+# stdout carries ONE JSON line, the headline, small enough to survive any tail of the output (round 5's single line had grown
+# to 20.9 KB and the driver's record lost its head): the contract fields, `config`, flat `roofline` / `roofline_other` /
+# `roofline_step`, `cpu_baseline`, and one short entry per secondary pair.  Each secondary pair's own compact line goes to
+# stderr BEFORE it (the reference prints its timings there too, src/util/timer.h:57-80), and the FULL record of everything --
+# plan, checks, instruction rooflines, the kernels on their share of the chip -- to the file named in `detail`.
+HEADLINE_MAX_BYTES = 6000
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "kernel_ms", "traffic_frac",
+             "traffic_frac_of_achievable", "frac_moved_bytes", "fetch_calibration", "limiter", "limiter_frac", "valu_busy_frac", "wait_frac",
+             "valu_per_query", "salu_per_query", "concurrent_with", "kernel_ms_alone", "frac_alone", "query_ms", "pmc_source")
+HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+             "data", "config", "ms_per_step_pipelined", "ms_per_step_synced", "pipelined", "ms_per_step_median", "ms_slowest_step",
+             "ms_per_step_pairs_only", "pip_gather_verified", "intersections", "intersections_per_query_segment", "lsi_points_ms",
+             "build_index_ms", "rebuild_index_ms", "index_slots_per_segment", "result_digest", "ranks", "multi_gpu_note")
+SECONDARY_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_pipelined", "intersections",
+                  "build_index_ms", "index_slots_per_segment")
+
+
+def flat_roofline(r, drop=()):
+    return {k: r[k] for k in ROOF_KEYS if k in r and k not in drop and not isinstance(r[k], dict)}
+
+
+def compact(line, secondary=False):
+    """the printed form of a full record: nothing nested deeper than `config` / a flat roofline / `cpu_baseline`"""
+    cfg = line["config"]
+    if secondary:
+        o = {k: line[k] for k in SECONDARY_KEYS if line.get(k) is not None}
+        o["line"] = "secondary"
+        o["kernel_schedule"] = cfg.get("kernel_schedule")
+        o["pip_passes"] = cfg.get("pip_passes")
+    else:
+        o = {k: line[k] for k in HEAD_KEYS if line.get(k) is not None or k == "vs_baseline"}
+        o["config"] = {k: cfg[k] for k in ("workload", "sharding", "kernel_schedule", "schedule_settled_before_timing", "pip_passes") if k in cfg}
+    for k in ("roofline", "roofline_other", "roofline_step"):
+        if k in line:
+            o[k] = flat_roofline(line[k], drop=("pmc_source",) if secondary else ())
+    if line.get("pip_caller_array"):
+        o["pip_caller_array_vs_map_owned"] = line["pip_caller_array"]["vs_map_owned"]
+    if line.get("checks") is not None:
+        o["checks_all_true"] = all(line["checks"].values())
+    if line.get("plan"):
+        o["plan_settled"] = bool(line["plan"].get("schedule", {}).get("settled"))
+    if "cpu_baseline" in line:
+        o["cpu_baseline"] = dict(line["cpu_baseline"])
+    return o
+
+
+def headline(out, sec, written):
+    """the ONE stdout line: the headline's compact form + one short entry per secondary pair + where the full record is"""
+    head = compact(out)
+    if sec:
+        head["secondary"] = {s["metric"].split(", ", 1)[1]: {
+            "ms_per_step": s["ms_per_step"], "ms_per_step_pipelined": s.get("ms_per_step_pipelined"), "kernel": s["roofline"]["kernel"],
+            "frac": s["roofline"]["frac"], "kernel_ms": s["roofline"]["kernel_ms"], "traffic": s["roofline"].get("traffic"),
+            "limiter": s["roofline"].get("limiter"), "cpu_baseline": (s.get("cpu_baseline") or {}).get("value")} for s in sec}
+    head["detail"] = written
+    text = json.dumps(head)
+    for k in ("multi_gpu_note", "result_digest", "secondary"):  # (never again a line whose head a tail cuts off: shed the longest first)
+        if len(text) <= HEADLINE_MAX_BYTES:
+            break
+        head.pop(k, None)
+        text = json.dumps(head)
+    return text
+
+
+def emit(out, sec, detail_path):
+    """rank 0: the full record to `detail_path`, each secondary pair's compact line to stderr, the headline to stdout -- last"""
+    written = None
+    try:
+        os.makedirs(os.path.dirname(os.path.abspath(detail_path)), exist_ok=True)
+        with open(detail_path, "w") as f:
+            json.dump({"headline": out, "secondary": sec}, f)
+        written = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT + os.sep) else detail_path
+    except OSError as e:   # (a read-only tree: the headline still goes out)
+        print("bench.py: could not write %s: %s" % (detail_path, e), file=sys.stderr)
+    for s in sec:
+        print(json.dumps(compact(s, secondary=True)), file=sys.stderr)
+    sys.stderr.flush()
+    print(headline(out, sec, written))
+    sys.stdout.flush()
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves -- torch.distributed.run as
     a CHILD process, before this process has imported torch or touched the GPU (no exec from a process that holds a GPU
@@ -684,6 +784,8 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    if args.gpus is None:  # (under a launcher without --gpus: its rank count; an EXPLICIT --gpus must agree with it, below)
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be at least 1")
     if "WORLD_SIZE" not in os.environ:
@@ -717,17 +819,13 @@ def main():
     out = run_workload(args, env, args.base, args.query, args.steps, args.warmup, True, with_cpu)
     # the harder pairs, in the same line: only on the default single-GPU run (each adds a few seconds)
     default_run = world == 1 and not args.emulate_shard and args.scale == 1.0 and (args.base, args.query) == ("USCounty", "BlockGroup")
+    sec = []
     if default_run and not args.no_secondary:
-        sec = []
         for b, q in SECONDARY:
             torch.cuda.empty_cache()
-            line = run_workload(args, env, b, q, max(5, min(args.steps, 10)), max(5, args.warmup), False, with_cpu)
-            sec.append({k: line[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_slowest_step", "config", "intersections", "intersections_per_query_segment",
-                                             "build_index_ms", "build_index_wall_ms", "rebuild_index_ms", "index_leaves", "index_slots_per_segment", "index_extras", "pip_caller_array", "ms_per_step_pipelined", "lsi_points_ms", "roofline", "roofline_other", "roofline_step",
-                                             "cpu_baseline") if k in line})
-        out["secondary"] = sec
+            sec.append(run_workload(args, env, b, q, max(5, min(args.steps, 10)), max(5, args.warmup), False, with_cpu))
     if rank == 0:
-        print(json.dumps(out))
+        emit(out, sec, args.detail)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

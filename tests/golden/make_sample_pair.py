@@ -5,6 +5,14 @@ its place, in the same role as test/test_overlay.sh's fixture + answer file).
 
 Answers come from the CPU oracle's -mode=grid restatement (oracle/), cross-checked against brute
 force before they are written.     python tests/golden/make_sample_pair.py
+
+ALL THREE ANSWER FILES ARE SELF-GENERATED: lsi_answer.txt, pip_answer.txt and overlay_answer.txt are
+what THIS repository's oracle pipeline (oracle/ + tests/overlay_ref.py) says, not output of the
+reference.  Byte-identity of the HIP path / the C++ writer with them is self-consistency of two
+independent implementations here; it is NOT parity with the reference's own
+test/dataset/br_countyXbr_soil_answer.txt, which is absent from the snapshot (.MISSING_LARGE_BLOBS).
+Only the LSI predicate, the rational store, calculate_cell and Scaling are pinned by the reference
+itself (tests/golden/lsi_ref_vectors.json, scaling_ref_vectors.json: DESIGN.md section 2).
 """
 import os
 import sys

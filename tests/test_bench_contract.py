@@ -10,8 +10,56 @@ def _latest_bench():
     return sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench.json")))[-1]
 
 
+def _load(path=None):
+    """the full record of the latest committed default run: since round 6 the file bench.py writes beside its one stdout line
+    ({"headline": ..., "secondary": [...]}); before, the single line itself with the secondaries inside"""
+    d = json.load(open(path or _latest_bench()))
+    if "headline" in d:
+        d = dict(d["headline"], secondary=d["secondary"])
+    return d
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)   # (imports numpy only: torch and the library are imported inside main())
+    return m
+
+
+def test_the_stdout_line_is_the_headline_alone_and_small(capsys, tmp_path):
+    """Round 5's single line had grown to 20.9 KB and the driver's record (the last 8 KB of stdout) lost the headline's
+    ms_per_step, roofline and cpu_baseline.  The line bench.py builds from the committed numbers must stay under 6 000 bytes,
+    be the LAST line of stdout -- the only one -- and carry the contract fields; the secondaries go to stderr before it."""
+    b = _bench_module()
+    d = _load()
+    sec = d.pop("secondary")
+    b.emit(d, sec, str(tmp_path / "detail.json"))
+    cap = capsys.readouterr()
+    lines = cap.out.strip().split("\n")
+    assert len(lines) == 1 and len(lines[0].encode()) <= b.HEADLINE_MAX_BYTES <= 6000
+    h = json.loads(lines[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "ms_per_step_pipelined", "ranks", "detail"):
+        assert k in h, k
+    for k in ("kernel", "achieved", "peak", "frac", "traffic", "algorithmic_bytes", "kernel_ms", "traffic_frac", "limiter", "pmc_source"):
+        assert k in h["roofline"], k
+    # nothing nested deeper than one level below the line (config, rooflines, cpu_baseline, ranks, the per-pair summary)
+    assert not any(isinstance(v2, dict) for k, v in h.items() if isinstance(v, dict) and k != "secondary" for v2 in v.values())
+    assert set(h["secondary"]) == {s["metric"].split(", ", 1)[1] for s in sec}
+    err = [json.loads(l) for l in cap.err.strip().split("\n") if l.startswith("{")]
+    assert [e["metric"] for e in err] == [s["metric"] for s in sec] and all(e["line"] == "secondary" and "roofline" in e and "cpu_baseline" in e for e in err)
+    full = json.load(open(tmp_path / "detail.json"))
+    assert full["headline"]["plan"] and len(full["secondary"]) == len(sec)
+    # the committed copy of the printed line, when the round has one
+    p = _latest_bench().replace("_bench.json", "_bench_line.json")
+    if os.path.exists(p):
+        raw = open(p).read().strip()
+        assert "\n" not in raw and len(raw.encode()) <= 6000 and json.loads(raw)["roofline"]["frac"] > 0
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(_latest_bench()))
+    d = _load()
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -24,7 +72,7 @@ def test_committed_bench_line_has_the_contract_fields():
     # round 3: the dominant kernel is the PIP walk; the line says what the number is (algorithmic bytes vs moved bytes)
     assert r["kernel"] in ("k_pip_walk", "k_pip_walk2", "k_pip_strip", "k_lsi", "k_lsi2") and "query_ms" in (r if r["kernel"].startswith("k_pip_") else d["roofline_other"])
     if r.get("traffic"):
-        assert 0 < r["traffic_frac"] < 1 and r["limiter"] in ("valu-issue", "dependent-load latency") and 0 < r["limiter_frac"] <= 1
+        assert 0 < r["traffic_frac"] < 1 and r["limiter"] in ("valu-issue", "dependent-load latency", "hbm-traffic") and 0 < r["limiter_frac"] <= 1
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -55,7 +103,7 @@ def test_committed_bench_line_has_the_contract_fields():
 def test_no_schedule_trials_inside_the_timed_region():
     """Under the driver's flags (--steps 20 --warmup 5) the kernel schedule must be settled before the first timed
     step: the committed line of exactly that command says so, and this fails if it ever does not."""
-    d = json.load(open(_latest_bench()))
+    d = _load()
     assert d["steps"] == 20 and d["warmup"] == 5
     assert d["config"]["schedule_settled_before_timing"] is True
     assert "undecided" not in d["config"]["kernel_schedule"]

@@ -23,8 +23,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_IN
 cd $R
 python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --regimes > gpurun_out/${TAG}_kernel_regimes.csv
 python3 tools/trace_tables.py gpurun_out/${TAG}_kt/g_kernel_trace.csv --steps 3 --skip 4 > gpurun_out/${TAG}_step_trace.txt
-timeout -k 10 500 python3 bench.py --check --steps 20 --warmup 5 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench.json
-tail -c 300 gpurun_out/${TAG}_bench.json || true
+# (the one stdout line = what the driver records; the full record -- secondaries, plan, checks -- is the --detail file)
+timeout -k 10 500 python3 bench.py --check --steps 20 --warmup 5 --detail gpurun_out/${TAG}_bench.json 2>gpurun_out/${TAG}_bench_stderr.txt | grep "^{" > gpurun_out/${TAG}_bench_line.json
+wc -c gpurun_out/${TAG}_bench_line.json; tail -c 300 gpurun_out/${TAG}_bench_line.json || true
 fi
 # Round 5: sections of counter passes beside the headline's full grids (tools/regime_probe.py: the profiler serialises
 # kernels, so a regime is profiled kernel by kernel on that regime's grids).  "shared" = the headline's kernels on the

@@ -10,6 +10,7 @@ rows = [("%s_bench.json", "USCounty ⋈ BlockGroup (headline)"), ("%s_bench_USCo
         ("%s_bench_BlockGroup_WaterBodiesLike.json", "BlockGroup ⋈ WaterBodiesLike")]
 for f, name in rows:
     d = json.load(open(os.path.join(R, f % tag)))
+    d = d.get("headline", d)   # (round 6: the --detail file; before: the single line)
     sched = d["config"]["kernel_schedule"]
     sched = ("shared " + sched[sched.index("(") + 1:sched.index(" blocks")]) if "share" in sched else ("turns" if "then" in sched else "full grids")
     cb = d.get("cpu_baseline") or {}

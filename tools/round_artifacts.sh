@@ -15,14 +15,14 @@ fi
 if [[ " $PARTS " == *" bench "* ]]; then
 for p in "USCounty Zipcode" "USCounty NestedBlockGroup" "WaterBodies BlockGroup" "LakesNA ParksNA" "Gaussian5M Gaussian1M" "WaterBodiesLike BlockGroup" "LakesLike ParksLike" "BlockGroup WaterBodiesLike"; do
   set -- $p
-  timeout -k 10 300 python3 bench.py --base $1 --query $2 --check --steps 20 --warmup 5 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench_$1_$2.json
+  timeout -k 10 300 python3 bench.py --base $1 --query $2 --check --steps 20 --warmup 5 --detail gpurun_out/${TAG}_bench_$1_$2.json 2>/dev/null | tail -c 400
   echo "bench $1 $2 done"
 done
 for n in 2 4 8; do
-  timeout -k 10 200 python3 bench.py --emulate-shard $n --steps 30 --warmup 6 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${TAG}_shard$n.json
+  timeout -k 10 200 python3 bench.py --emulate-shard $n --steps 30 --warmup 6 --no-cpu-baseline --detail gpurun_out/${TAG}_shard$n.json 2>/dev/null | tail -c 300
 done
-timeout -k 10 200 python3 bench.py --base WaterBodies --query BlockGroup --emulate-shard 8 --steps 30 --warmup 6 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${TAG}_wb_shard8.json
-timeout -k 10 200 python3 bench.py --serial-kernels --no-secondary --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/${TAG}_bench_serial.json
+timeout -k 10 200 python3 bench.py --base WaterBodies --query BlockGroup --emulate-shard 8 --steps 30 --warmup 6 --no-cpu-baseline --detail gpurun_out/${TAG}_wb_shard8.json 2>/dev/null | tail -c 300
+timeout -k 10 200 python3 bench.py --serial-kernels --no-secondary --steps 20 --warmup 5 --no-cpu-baseline --detail gpurun_out/${TAG}_bench_serial.json 2>/dev/null | tail -c 300
 echo "shards done"
 fi
 if [[ " $PARTS " == *" probes "* ]]; then
