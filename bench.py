@@ -44,7 +44,12 @@ HBM_ACHIEVABLE_GBS = 6290.0  # measured streaming rate, same guide ("Chip-level 
 # the harder pairs that ride in the default line: nested maps (shared vertices), the 4-level WaterBodies lattice, and a
 # LAKE-SHAPED base map (2.44 M isolated rings of ~10 edges: the topology the reference's water-body / lake / park
 # inputs have and no lattice has -- short rings sharing leaves, a third of the query vertices with nothing above them)
-CPU_SAMPLE = {("WaterBodiesLike", "BlockGroup"): 0.4, ("LakesLike", "ParksLike"): 0.4}  # fraction of the resolution the CPU baseline runs at
+# The CPU baseline runs the WHOLE workload of every pair (round 5 ran the ring pairs at 0.4 of the lattice resolution: the oracle's
+# grid PIP -- faithful to src/app/pip_grid.h:48 -- walks every cell above a point that has nothing above it, a third of the
+# lattice's vertices against a lake-shaped base map: 36 s at the default grid_size 2048).  A finer grid cuts that walk (4x the
+# rows above a miss, 1/16 of the edges in each) and changes no result (grid output is independent of -grid_size:
+# tests/test_oracle_maps.py); the paper's own scripts run -grid_size=15000 (expr/env.sh).  The line says which size was used.
+CPU_GRID = {("WaterBodiesLike", "BlockGroup"): 8192, ("LakesLike", "ParksLike"): 8192}
 # ... and, since round 5, a Zipcode-sized query map that CROSSES the county boundaries at the density of the reference's own
 # logs (County x Zipcode: 833 470 intersections / 23.76 M query segments = 3.5 %; the headline's independent
 # lattices give 0.65 %): the stand-ins were kind on exactly this count
@@ -87,9 +92,7 @@ def cpu_baseline(args, ctx, base_name, query_name):
     from rayjoin_amd import maps, synth
     # all host cores this process may use, capped: the GPU box is shared
     O.lib().rjo_set_num_threads(max(1, min(64, len(os.sched_getaffinity(0)))))
-    # (a bounded sample where the whole workload would take the host minutes: the oracle's grid PIP walks every cell above
-    #  a point that has nothing above it -- a third of the lattice's vertices against the lake-shaped base map: 36 s)
-    cpu_scale = args.cpu_scale * CPU_SAMPLE.get((base_name, query_name), 1.0)
+    cpu_scale = args.cpu_scale
     if cpu_scale != 1.0:
         g0 = synth.standin(base_name, cpu_scale * args.scale)
         g1 = synth.standin(query_name, cpu_scale * args.scale)
@@ -97,7 +100,7 @@ def cpu_baseline(args, ctx, base_name, query_name):
     m0 = O.Map(ctx.maps[0].pts, ctx.maps[0].row_index, ctx.maps[0].left, ctx.maps[0].right)
     m1 = O.Map(ctx.maps[1].pts, ctx.maps[1].row_index, ctx.maps[1].left, ctx.maps[1].right)
     L = O.lib()
-    gsize = 2048  # src/flags.cc:6 default
+    gsize = int(os.environ.get("RJ_BENCH_CPU_GRID", 0)) or CPU_GRID.get((base_name, query_name), 2048)  # 2048: src/flags.cc:6 default
     t0 = time.perf_counter()
     grid = L.rjo_grid_build(m0.h, m1.h, gsize)
     t_build = time.perf_counter() - t0
@@ -144,6 +147,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
 
     h = _capi.Handle(local_rank)
     h.set_stream(torch.cuda.current_stream().cuda_stream)
+    for kv in filter(None, os.environ.get("RJ_BENCH_DEBUG_OPTS", "").split(",")):  # (A/B runs: "run_cap=16,strip_shift=16" -> rj_set_debug_option)
+        h.set_debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     t0 = time.perf_counter()
     h.upload_map(0, base.pts, base.row_index, base.left, base.right)
     h.upload_map(1, query.pts, query.row_index, query.left, query.right)

@@ -65,6 +65,8 @@ struct BvhState {
   uint4* strip_info = nullptr;   // [strip_cap] {slot, edge id, face id, 0} per entry
   uint2* strip_tall = nullptr;   // [strips] {tallest box, end of the strip's entries}
   int strip_shift = 0;           // a strip is 2^strip_shift quanta wide (chosen by the map's segments, build_strips)
+  bool ysort = false;            // the leaves' blocks may be ordered by y (k_build_leaves: blocks taller than wide)
+  const char* columns_why = "";  // rj_get_plan: on what grounds the last build made (or did not make) the column index
   int strip_tab_shift = 0;       // ... and the width strip_tall / strip_ytab are allocated for (0: not yet)
   QBox* strip_box = nullptr;
   uint64_t strip_entries = 0, strip_cap = 0;
@@ -198,6 +200,8 @@ struct rj_handle_s {
   int debug_stack_cap = 1 << 30;            // tests of the fault path only
   int debug_walk_stack = 0;                 // tests of the groups that leave the walk (0: kWalkStack entries)
   int debug_strip_shift = 0;                // the column index of the next build on strips of 2^this quanta (0: by the map)
+  int debug_query_key_strips = 0;           // experiment: a re-ordered PIP query set over a column index is sorted strip-major (strip, then y), not by Morton key
+  int order_strip_shift = 0;                // ... the strip width the next query-key pass sorts by (0: Morton keys)
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
@@ -249,8 +253,9 @@ struct rj_handle_s {
   uint32_t stitch_stats[4] = {0, 0, 0, 0};  // the last run cutting: ranking rounds, incidences on closed loops, rounds of the second ranking, closed chains
   char* strip_scratch = nullptr;  // grow-only temporaries of the column index's build
   size_t strip_scratch_bytes = 0;
-  int pip_columns = -1;      // "pip_columns": -1 auto (maps of isolated rings), 0 never, 1 always -- the column index of the NEXT rj_build_lbvh
+  int pip_columns = -1;      // "pip_columns": -1 auto (maps of closed rings or of short chains), 0 never, 1 always -- the column index of the NEXT rj_build_lbvh
   int last_columns = 0;      // the last PIP query's first pass ran on the column index
+  int leaf_ysort = -1;       // "leaf_ysort": -1 auto (where the NEXT rj_build_lbvh also builds a column index: the leaves serve LSI only), 0 never, 1 always -- blocks taller than wide are ordered by y
   int skyline = -1;          // "skyline": -1 auto (maps of isolated rings), 0 never, 1 always -- what the NEXT rj_build_lbvh does
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
@@ -514,6 +519,8 @@ int rj_create(int device_id, rj_handle* out) {
   if (const char* e = getenv("RJ_LSI_SEGMENTS")) h->lsi_segments = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
   if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : (atoi(e) == 4 ? 4 : 2);  // (A/B runs)
   if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
+  if (const char* e = getenv("RJ_LEAF_YSORT")) { const int v = atoi(e); h->leaf_ysort = v < -1 || v > 1 ? -1 : v; }      // (A/B runs)
+  if (const char* e = getenv("RJ_PIP_COLUMNS")) { const int v = atoi(e); h->pip_columns = v < -1 || v > 1 ? -1 : v; }    // (A/B runs: the column index on / off whatever the map)
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) h->cus = prop.multiProcessorCount;
@@ -673,6 +680,8 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "stitch_loop_ends")) *value = h->stitch_stats[1];   // ... chain ends on closed loops of paired chains
   else if (!strcmp(name, "skyline")) *value = h->skyline;
   else if (!strcmp(name, "pip_columns")) *value = h->pip_columns;
+  else if (!strcmp(name, "leaf_ysort")) *value = h->leaf_ysort;
+  else if (!strcmp(name, "leaf_ysort_used0") || !strcmp(name, "leaf_ysort_used1")) *value = h->bvh[name[15] - '0'].ysort ? 1 : 0;
   else if (!strcmp(name, "pip_columns_used0") || !strcmp(name, "pip_columns_used1")) *value = h->bvh[name[16] - '0'].strips_built ? 1 : 0;
   else if (!strcmp(name, "pip_column_entries0") || !strcmp(name, "pip_column_entries1")) *value = (int64_t) h->bvh[name[18] - '0'].strip_entries;
   else if (!strcmp(name, "pip_column_shift0") || !strcmp(name, "pip_column_shift1")) *value = h->bvh[name[16] - '0'].strips_built ? h->bvh[name[16] - '0'].strip_shift : 0;
@@ -712,9 +721,13 @@ int rj_get_plan(rj_handle h, char* buf, size_t cap, size_t* need) {
   add(", \"index\": [");
   for (int m = 0; m < 2; m++) {
     const BvhState& b = h->bvh[m];
-    add("%s{\"map\": %d, \"built\": %s, \"levels\": %d, \"slots\": %llu, \"leaves\": \"%s\", \"skyline\": %s, \"columns\": %s, \"column_shift\": %d}",
+    add("%s{\"map\": %d, \"built\": %s, \"levels\": %d, \"slots\": %llu, \"leaves\": \"%s\", \"skyline\": %s, \"columns\": %s, \"column_shift\": %d, "
+        "\"steep_blocks_sorted_by_y\": %s, \"mean_chain_edges\": %.1f, \"slots_per_segment\": %.3f, \"columns_why\": \"",
         m ? ", " : "", m, b.built ? "true" : "false", b.top, (unsigned long long) b.n0p, b.leaf_order == 1 ? "polyline runs" : "Hilbert neighbours",
-        b.use_sky ? "true" : "false", b.strips_built ? "true" : "false", b.strips_built ? b.strip_shift : 0);
+        b.use_sky ? "true" : "false", b.strips_built ? "true" : "false", b.strips_built ? b.strip_shift : 0, b.ysort ? "true" : "false",
+        h->map[m].nc ? (double) h->map[m].ne / (double) h->map[m].nc : 0.0, b.n0 ? (double) b.n0p / (double) b.n0 : 0.0);
+    for (const char* c = b.built ? b.columns_why : ""; *c; c++) { if (*c == '"') o += '\\'; o += *c; }  // (JSON string: quotes escaped)
+    o += "\"}";
   }
   add("]");
   // the schedule of an LSI + PIP pair
@@ -796,8 +809,13 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     h->skyline = (int) value;
     return RJ_OK;
   }
+  if (!strcmp(name, "leaf_ysort")) {
+    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "leaf_ysort: -1 auto (maps that get a column index), 0 never, 1 always");
+    h->leaf_ysort = (int) value;
+    return RJ_OK;
+  }
   if (!strcmp(name, "pip_columns")) {
-    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "pip_columns: -1 auto (maps of isolated rings), 0 never, 1 always");
+    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "pip_columns: -1 auto (maps of closed rings or of short chains), 0 never, 1 always");
     h->pip_columns = (int) value;
     return RJ_OK;
   }
@@ -863,6 +881,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
       {"stack_cap", &h->debug_stack_cap, 1, 1 << 30},     // instrumented kernels: fewer traversal-stack entries (fault path)
       {"walk_stack", &h->debug_walk_stack, 0, 1 << 30},   // k_pip_walk*: fewer stack entries (groups that need more leave the walk)
       {"strip_shift", &h->debug_strip_shift, 0, 20},      // the column index on strips of 2^this quanta (0: chosen by the map; 15..20)
+      {"query_key_strips", &h->debug_query_key_strips, 0, 1},  // "query_order" 2 over a column index: sort the points strip-major instead of by Morton key
       {"run_cap", &h->debug_run_cap, 0, 64},              // edges per polyline run of the next first build of a map (0: 64)
       {"pack_solo", &h->debug_pack_solo, 0, 64},          // a run longer than this never shares its leaf (0: 48)
       {"pack_spread", &h->debug_pack_spread, 0, 1000000}, // a shared leaf may be this many times as large as its runs (0: 8)
@@ -1047,11 +1066,18 @@ static int ensure_sort_scratch(rj_handle h, uint64_t n) {
 static int build_strips(rj_handle h, BvhState& b, bool with_sky) {
   b.strips_built = false;
   auto up = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+  // (an allocation that fails is not the build's failure unless the caller FORCED the column index: the tree is built
+  //  and serves the map alone -- RJ_E_NOMEM only under "pip_columns" 1)
+  const bool forced = h->pip_columns == 1;
   auto scratch = [&](size_t bytes) -> int {
     if (bytes <= h->strip_scratch_bytes) return RJ_OK;
     (void) hipFree(h->strip_scratch);
     h->strip_scratch = nullptr; h->strip_scratch_bytes = 0;
-    RJ_HIP(h, hipMalloc((void**) &h->strip_scratch, bytes));
+    const hipError_t e = hipMalloc((void**) &h->strip_scratch, bytes);
+    if (e != hipSuccess) {
+      (void) hipGetLastError();
+      return forced ? fail(h, RJ_E_NOMEM, "rj_build_lbvh: %zu bytes of scratch for the column index: %s", bytes, hipGetErrorString(e)) : -1;
+    }
     h->strip_scratch_bytes = bytes;
     return RJ_OK;
   };
@@ -1075,13 +1101,17 @@ static int build_strips(rj_handle h, BvhState& b, bool with_sky) {
   {
     // everything both passes need, for an estimate of 2 entries per slot (the lake-shaped maps have 1.5): the counts then
     // stay where they are when the total arrives (a first build used to count and scan twice: 0.27 ms)
-    const size_t est = 2 * (size_t) b.n0p;
+    // (... per SLOT, or 2.5 per real segment where the leaves are half empty -- the short-chain lattices' 2.12 slots per
+    //  segment: 2 x 51.8 M slots for 24.4 M segments that make 44 M entries)
+    const size_t est = 2 * (size_t) b.n0p < 5 * (size_t) b.n0 / 2 + 64 ? 2 * (size_t) b.n0p : 5 * (size_t) b.n0 / 2 + 64;
     size_t est_sort = 0;
     RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, b.n0p, shift, est, nullptr, nullptr, nullptr, nullptr, nullptr,
                                 nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, est_sort));
-    const size_t both = 2 * cnt_bytes + 256 + 2 * up(8 * est) + 2 * up(4 * est) + up(4 * (size_t) strips) + up(est_sort);
+    const size_t both = 2 * cnt_bytes + 256 + 4 * up(4 * est) + up(4 * (size_t) strips) + up(est_sort);  // (keys are 32-bit since round 5)
     const size_t first = 2 * cnt_bytes + 256 + up(scan_bytes);
-    if (int r = scratch(both > first ? both : first)) return r;
+    if (int r = scratch(both > first ? both : first)) {
+      if (r > 0 || (r = scratch(first))) return r < 0 ? RJ_OK : r;  // (the estimate did not fit: count first, size then -- or leave it to the tree)
+    }
   }
   uint32_t* cnt = (uint32_t*) h->strip_scratch;
   uint32_t* offs = (uint32_t*) (h->strip_scratch + cnt_bytes);
@@ -1098,11 +1128,13 @@ static int build_strips(rj_handle h, BvhState& b, bool with_sky) {
   size_t sort_bytes = 0;
   RJ_HIP(h, launch_strip_fill(h->stream, nullptr, nullptr, nullptr, nullptr, nullptr, b.n0p, shift, total, nullptr, nullptr, nullptr, nullptr, nullptr,
                               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sort_bytes));
-  const size_t need = 2 * cnt_bytes + 256 + 2 * up(8 * (size_t) total) + 2 * up(4 * (size_t) total) + up(4 * (size_t) strips) + up(sort_bytes);
+  const size_t need = 2 * cnt_bytes + 256 + 4 * up(4 * (size_t) total) + up(4 * (size_t) strips) + up(sort_bytes);
   if (need > h->strip_scratch_bytes) {
     // (the counts live in the scratch block that is about to move: count again into the new one -- first build of a
     //  larger map only)
-    if (int r = scratch(need + need / 8)) return r;
+    if (int r = scratch(need + need / 8)) {
+      if (r > 0 || (r = scratch(need))) return r < 0 ? RJ_OK : r;
+    }
     cnt = (uint32_t*) h->strip_scratch; offs = (uint32_t*) (h->strip_scratch + cnt_bytes); flag = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes);
     temp = h->strip_scratch + 2 * cnt_bytes + 256;
     tb = scan_bytes;
@@ -1110,8 +1142,8 @@ static int build_strips(rj_handle h, BvhState& b, bool with_sky) {
   }
   // (32-bit keys since round 5 -- strip above the band of y0, rj_strip.hip -- in the room the 64-bit ones had)
   uint32_t* key_tmp = (uint32_t*) (h->strip_scratch + 2 * cnt_bytes + 256);
-  uint32_t* key = (uint32_t*) ((char*) key_tmp + up(8 * (size_t) total));
-  uint32_t* slot_tmp = (uint32_t*) ((char*) key + up(8 * (size_t) total));
+  uint32_t* key = (uint32_t*) ((char*) key_tmp + up(4 * (size_t) total));
+  uint32_t* slot_tmp = (uint32_t*) ((char*) key + up(4 * (size_t) total));
   uint32_t* slot_sorted = (uint32_t*) ((char*) slot_tmp + up(4 * (size_t) total));
   uint32_t* tall_tmp = (uint32_t*) ((char*) slot_sorted + up(4 * (size_t) total));
   temp = (char*) tall_tmp + up(4 * (size_t) strips);
@@ -1321,9 +1353,15 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     // stand-in, 240 leaf blocks opened for each).  So: built where most chains are closed rings.
     // (filled below: by the column index's own pass where the map gets one, else by a pass over the leaves' boxes)
     b.use_sky = false;
+    {
+      // (the blocks' sort axis: y for steep blocks where the PIP query will run on the column index built below and the
+      //  leaves serve LSI alone -- "leaf_ysort", k_build_leaves)
+      const bool columns_coming = h->pip_columns == 1 || (h->pip_columns < 0 && m.runs_cut && m.nc && (2 * m.closed_chains >= m.nc || m.ne / m.nc < 16));
+      b.ysort = h->leaf_ysort == 1 || (h->leaf_ysort < 0 && columns_coming);
+    }
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, nruns ? m.piece_begin : nullptr,
                                  m.piece_len, m.run_first, m.run_len, m.leaf_first, b.n0p / 64, b.alloc[1],
-                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ)) != hipSuccess) break;
+                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ, b.ysort)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
     const QBox* child = b.lvl[1];
@@ -1342,10 +1380,23 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
   RJ_HIP(h, e);
   // The column index (rj_device.h DeviceStrips), where the tree is at its worst for upward rays: maps of isolated rings
   // (the criterion of the skyline).  Two passes over the sorted slots around a radix sort of the (strip, y0) entries.
+  // Round 6, a second class, from the build's own statistics: maps of SHORT CHAINS (mean chain length below 16 edges -- the
+  // test that already halves the run cap above; the WaterBodies lattice: 10-edge chains, 2.12 slots per segment, fat leaves).
+  // Measured on one box, WaterBodies x BlockGroup: first pass alone 1.28 (walk) -> 0.97 ms (columns), step 2.45 -> 2.17 ms;
+  // the build pays 3.4 ms for it (first 5.9 -> 9.3, rebuild 2.3 -> 5.6), i.e. from the twelfth step of a map on.  On lattices
+  // of LONG chains the walk stays: forced there the columns lose (USCounty 0.54 -> 1.21 ms alone, step 0.77 -> 1.35; LakesNA
+  // step 2.32 -> 2.35 and 100 ms of first build) -- profiles/r06_columns_ab.txt.
   b.strips_built = false;
-  const bool want_sky = h->skyline == 1 || (h->skyline < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc);
-  if (h->pip_columns == 1 || (h->pip_columns < 0 && m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc)) {
+  const bool rings = m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc;
+  const bool short_chains = m.runs_cut && m.nc && m.ne / m.nc < 16;
+  const bool want_sky = h->skyline == 1 || (h->skyline < 0 && rings);
+  b.columns_why = h->pip_columns == 0 ? "off (\"pip_columns\" 0)" : "the map's chains are long open polylines: the tree walk is the faster first pass";
+  if (h->pip_columns == 1 || (h->pip_columns < 0 && (rings || short_chains))) {
     if (int r = build_strips(h, b, want_sky)) return r;
+    b.columns_why = !b.strips_built ? "wanted, not built (a segment spans too many strips, or no memory for it): the tree serves the map"
+                    : h->pip_columns == 1 ? "forced (\"pip_columns\" 1)"
+                    : rings ? "most chains are closed rings (the tree is at its worst for upward rays there)"
+                            : "short chains (mean chain length below 16 edges: fat leaves, measured rule of round 6)";
   }
   if (want_sky && !b.use_sky) {
     RJ_HIP(h, hipMemsetAsync(b.sky, 0, ((size_t) kSkyBuckets + 1) * 4, h->stream));
@@ -1366,7 +1417,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
 static int sort_query_points(rj_handle h, const int64_t* pts, uint64_t n) {  // -> h->ord_vout
   if (int r = ensure_sort_scratch(h, n)) return r;
   tic(h, RJ_T_ORDER);
-  RJ_HIP(h, launch_query_keys(h->stream, true, pts, nullptr, 0, n, h->ord_kin, h->ord_vin));
+  RJ_HIP(h, launch_query_keys(h->stream, true, pts, nullptr, 0, n, h->ord_kin, h->ord_vin, h->order_strip_shift));
   size_t tb = h->ord_temp_bytes;
   RJ_HIP(h, sort_morton_pairs(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
   toc(h, RJ_T_ORDER);
@@ -1475,7 +1526,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
   if (int r = ensure_sort_scratch(h, n)) return r;
   h->order_fresh = true;
   tic(h, RJ_T_ORDER);
-  RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin));
+  RJ_HIP(h, launch_query_keys(h->stream, points, pts, segs, begin, n, h->ord_kin, h->ord_vin, points ? h->order_strip_shift : 0));
   size_t tb = h->ord_temp_bytes;
   RJ_HIP(h, sort_morton_pairs(h->stream, h->ord_temp, tb, h->ord_kin, h->ord_kout, h->ord_vin, h->ord_vout, n));
   toc(h, RJ_T_ORDER);
@@ -1724,6 +1775,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   // (a base map with a column index answers every point on its own -- nothing is shared between the points of a wave,
   //  so a scattered query set needs no re-ordering there)
   const bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && (!h->stats_on || h->pip_walk == 2);
+  h->order_strip_shift = by_columns && h->debug_query_key_strips ? h->bvh[base_map_id].strip_shift : 0;
   if (by_columns && h->query_order != 2) { h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr; }
   else if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
   // "pip_concurrent": the kernel goes to the handle's second stream and runs BESIDE the LSI kernel
@@ -1911,7 +1963,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     }
     h->flip_pip[si] = 1 - pflip;
     h->plan.pip.exact_blocks = h->cus * 8; h->plan.pip.locate_blocks = rest_blocks;
-    if (columns) why = "the base map has a column index (a map of closed rings): the first pass reads the point's strip";
+    if (columns) why = "the base map has a column index (closed rings or short chains: index[].columns_why): the first pass reads the point's strip";
     else if (!two && h->walk_points >= 2) why = "one point per lane: a query set too small for full groups on every resident wave (or a debug knob set)";
   } else if (n) {
     // (k_pip uses the scheduler block the last exact kernel of this stream used or cleared)

@@ -134,6 +134,13 @@ __host__ __device__ __forceinline__ int leaf_bucket_shift(uint32_t extent_minus_
   if (extent_minus_1 < 256u) return 0;
   return 24 - __builtin_clz(extent_minus_1);  // (extent_minus_1 >> shift) < 256
 }
+// A leaf block's SORT AXIS (k_build_leaves): blocks are ordered by x0 (prefix max of x1, bucket table on x) -- or, where the
+// map's PIP query has a column index and the block is taller than wide, by y0 (prefix max of y1, table on y).  The flag is
+// the one spare bit of the table: bit 31 of lane 63's second word (the counts there are <= 64).
+constexpr uint32_t kLeafYSortBit = 0x80000000u;
+__device__ __forceinline__ bool leaf_ysort(const uint2& tab_of_this_lane) {
+  return ((uint32_t) __builtin_amdgcn_readlane((int) tab_of_this_lane.y, 63) & kLeafYSortBit) != 0u;
+}
 __device__ __forceinline__ const uint64_t* sibling_order(const DeviceBvh& T, int l) {
   return T.ord[l];  // (= lvl[l] + pad64(nlvl[l]): one scalar load instead of a dozen scalar instructions per node expansion)
 }

@@ -151,7 +151,7 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
                                const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* run_len, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ);
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, bool allow_ysort = false);
 hipError_t launch_build_sky(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* sky);
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,
@@ -165,7 +165,7 @@ hipError_t launch_group_extent(hipStream_t st, bool points, const int64_t* pts, 
                                uint64_t n, unsigned long long* out2);
 hipError_t launch_group_extent_tail(hipStream_t st, const int64_t* pts, const uint32_t* order, uint64_t n, unsigned long long* out_mapped);
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
-                             uint64_t n, MortonKey* keys, uint32_t* vals);
+                             uint64_t n, MortonKey* keys, uint32_t* vals, int strip_shift = 0);
 hipError_t launch_lsi_points(hipStream_t st, const Seg* seg0, const Seg* seg1, const uint32_t* pairs,
                              uint64_t n, const unsigned long long* n_dev, XsectRec* out, uint32_t* slow_list,
                              unsigned long long* slow_count, unsigned long long* next_slow_count,

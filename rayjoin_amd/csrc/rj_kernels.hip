@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
                                                       int32_t* __restrict__ pmx1, uint2* __restrict__ xtab,
-                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ) {
+                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ, int allow_ysort) {
   __shared__ int32_t sx1[4][64];
   __shared__ uint4 hist[4][64];  // 256 x-bucket counters per wave
   const int lane = lane_id();
@@ -407,17 +407,27 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
       b.y1 = quant(s.y1 < s.y2 ? s.y2 : s.y1);
     }
     mark_occupancy_wave(b, valid, occ, lane);
+    const int32_t ux0 = wave_min(b.x0), uy0 = wave_min(b.y0), ux1 = wave_max(b.x1), uy1 = wave_max(b.y1);
+    // The block's SORT AXIS (round 6).  x where upward rays use the block (every map without a column index): a point's
+    // candidates are the slots over its x.  Where the PIP query has a column index instead (allow_ysort: maps of closed rings
+    // or of short chains) the block only serves LSI, and a block that is TALLER than wide -- a steep run of a polyline stitched
+    // from short chains folds back and forth in x, every edge over every query's x-range -- is ordered by y0 instead, prefix
+    // max and bucket table on y: a query segment's scan is the slots over its Y-range.  Flagged in the one spare bit of the
+    // table (bit 31 of lane 63's second word: counts are <= 64); the PIP traversals scan such a block whole.
+    const bool ysort = allow_ysort && (uint32_t) (uy1 - uy0) > (uint32_t) (ux1 - ux0);
+    const int32_t a0 = ysort ? b.y0 : b.x0, a1 = ysort ? b.y1 : b.x1;
+    const int32_t ua0 = ysort ? uy0 : ux0, ua1 = ysort ? uy1 : ux1;
     int rank = 0;
     for (int k = 0; k < 64; k++) {
-      const int32_t xk = bcast(b.x0, k);
-      rank += (xk < b.x0 || (xk == b.x0 && k < lane)) ? 1 : 0;
+      const int32_t xk = bcast(a0, k);
+      rank += (xk < a0 || (xk == a0 && k < lane)) ? 1 : 0;
     }
     const uint64_t o = blk * 64 + rank;
     sseg[o] = s;
     seid[o] = id;
     sface[o] = fc;
     box0[o] = b;
-    sx1[wib][rank] = b.x1;
+    sx1[wib][rank] = a1;
     wave_lds_fence();
     int32_t m = sx1[wib][lane];
 #pragma unroll
@@ -425,9 +435,8 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
       int32_t t = __shfl_up(m, d, 64);
       if (lane >= d) m = t > m ? t : m;
     }
-    pmx1[blk * 64 + lane] = m;
+    pmx1[blk * 64 + lane] = ysort ? 0x7FFFFFFF : m;  // (read by k_pip's locate only, which needs the x order: "never ends" = test every slot)
     wave_lds_fence();
-    const int32_t ux0 = wave_min(b.x0), uy0 = wave_min(b.y0), ux1 = wave_max(b.x1), uy1 = wave_max(b.y1);
     if (lane == 0) lvl1[blk] = QBox{ux0, uy0, ux1, uy1};
     // x-bucket table (k_pip_walk): 256 buckets over the block's x-extent.  The block is x0-sorted, so the segments
     // that can contain a point of bucket b in x are the slots [lo_b, hi_b): hi_b = how many segments START in a
@@ -435,7 +444,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     // those are the first slots).  Two histograms + two prefix sums; the point's scan needs no search for its
     // first slot and no prefix-max fetch to know its last.
     {
-      const int sh = leaf_bucket_shift((uint32_t) (ux1 - ux0));
+      const int sh = leaf_bucket_shift((uint32_t) (ua1 - ua0));
       const int nvalid = __popcll(__ballot(valid));
       uint32_t* hw = reinterpret_cast<uint32_t*>(&hist[wib][0]);
       uint32_t packed[2];
@@ -446,8 +455,8 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
         // pass 0: by the bucket of x0 (this lane's own segment); pass 1: by the bucket of the prefix max of slot `lane`
         // (padding slots sort last and count in neither: a point never scans them)
         const bool use = pass == 0 ? valid : lane < nvalid;
-        const int32_t v = pass == 0 ? b.x0 : m;
-        if (use) atomicAdd(&hw[(uint32_t) (v - ux0) >> sh], 1u);
+        const int32_t v = pass == 0 ? a0 : m;
+        if (use) atomicAdd(&hw[(uint32_t) (v - ua0) >> sh], 1u);
         wave_lds_fence();
         const uint4 c = hist[wib][lane];
         const uint32_t p0 = c.x, p1 = p0 + c.y, p2 = p1 + c.z, p3 = p2 + c.w;
@@ -463,7 +472,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                  : exc | ((exc + p0) << 8) | ((exc + p1) << 16) | ((exc + p2) << 24);
         wave_lds_fence();
       }
-      xtab[blk * 64 + lane] = make_uint2(packed[0], packed[1]);
+      xtab[blk * 64 + lane] = make_uint2(packed[0], packed[1] | ((ysort && lane == 63) ? kLeafYSortBit : 0u));
       wave_lds_fence();
     }
   }
@@ -630,7 +639,7 @@ __global__ __launch_bounds__(1024) void k_group_extent_tail(const int64_t* __res
 template <bool POINTS>
 __global__ __launch_bounds__(256) void k_query_keys(const int64_t* __restrict__ pts, const Seg* __restrict__ segs,
                                                     uint64_t begin, uint64_t n, MortonKey* __restrict__ keys,
-                                                    uint32_t* __restrict__ vals) {
+                                                    uint32_t* __restrict__ vals, int strip_shift) {
   for (uint64_t i = blockIdx.x * (uint64_t) blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
     int64_t mx, my;
     if (POINTS) {
@@ -638,6 +647,14 @@ __global__ __launch_bounds__(256) void k_query_keys(const int64_t* __restrict__ 
     } else {
       const Seg s = segs[begin + i];
       mx = (s.x1 + s.x2) >> 1; my = (s.y1 + s.y2) >> 1;
+    }
+    if (strip_shift) {
+      // STRIP-MAJOR order (a PIP query over a column index, rj_strip.hip): the point's strip above its height -- consecutive
+      // positions then read consecutive places of ONE strip's table and list
+      const int nb = 31 - strip_shift;  // bits of strip
+      keys[i] = (MortonKey) ((((uint32_t) quant(mx) >> strip_shift) << (32 - nb)) | ((uint32_t) quant(my) >> (nb - 1)));
+      vals[i] = (uint32_t) i;
+      continue;
     }
     const uint32_t ux = (uint32_t) ((uint64_t) (mx + kCoordOffset) >> 15), uy = (uint32_t) ((uint64_t) (my + kCoordOffset) >> 15);
     keys[i] = (MortonKey) (((spread32(uy) << 1) | spread32(ux)) >> kMortonDropBits);
@@ -901,13 +918,16 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         // x-extent (what the table was built on) is re-derived from its boxes: padding slots are empty boxes.
         const uint32_t slot0 = idx * 64;
         if (STATS) st_leaf++;
-        const int32_t lx0 = wave_min(b.x0), lx1 = wave_max(b.x1);
+        // (the block's sort axis: x, or -- a steep block of a map whose PIP query has a column index -- y: k_build_leaves)
+        const bool ysort = leaf_ysort(tab);
+        const int32_t lx0 = wave_min(ysort ? b.y0 : b.x0), lx1 = wave_max(ysort ? b.y1 : b.x1);
         const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
-        const int32_t ca = qx0 > lx0 ? qx0 : lx0, cz = qx1 < lx1 ? qx1 : lx1;  // the query's x-range inside the block's
+        const int32_t qa0 = ysort ? qy0 : qx0, qa1 = ysort ? qy1 : qx1;
+        const int32_t ca = qa0 > lx0 ? qa0 : lx0, cz = qa1 < lx1 ? qa1 : lx1;  // the query's range on that axis inside the block's
         const bool some = ca <= cz;                                           // (idle lanes: qx0 > qx1)
         const uint32_t bhi = some ? (uint32_t) (cz - lx0) >> sh : 0u, blo = some ? (uint32_t) (ca - lx0) >> sh : 0u;
-        const uint32_t hi = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (bhi >> 2) << 2, (int) tab.x) >> ((bhi & 3u) * 8u)) & 0xFFu;
-        const uint32_t lo = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (blo >> 2) << 2, (int) tab.y) >> ((blo & 3u) * 8u)) & 0xFFu;
+        const uint32_t hi = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (bhi >> 2) << 2, (int) tab.x) >> ((bhi & 3u) * 8u)) & 0x7Fu;
+        const uint32_t lo = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (blo >> 2) << 2, (int) tab.y) >> ((blo & 3u) * 8u)) & 0x7Fu;
         int j = some ? (int) hi - 1 : -1;
         const int jlo = some ? (int) lo : 0;
         while (__ballot(j >= jlo)) {
@@ -1079,16 +1099,18 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         wave_lds_fence();
       } else {
         const uint32_t slot0 = idx * 64;
-        const int32_t lx0 = wave_min(b.x0), lx1 = wave_max(b.x1);
+        const bool ysort = leaf_ysort(tab);  // (the block's sort axis: k_build_leaves)
+        const int32_t lx0 = wave_min(ysort ? b.y0 : b.x0), lx1 = wave_max(ysort ? b.y1 : b.x1);
         const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-          const int32_t ca = qx0[p] > lx0 ? qx0[p] : lx0, cz = qx1[p] < lx1 ? qx1[p] : lx1;
+          const int32_t qa0 = ysort ? qy0[p] : qx0[p], qa1 = ysort ? qy1[p] : qx1[p];
+          const int32_t ca = qa0 > lx0 ? qa0 : lx0, cz = qa1 < lx1 ? qa1 : lx1;
           const bool some = ca <= cz;
-          if (!__ballot(some)) continue;  // none of this set's segments reaches into the block's x-range
+          if (!__ballot(some)) continue;  // none of this set's segments reaches into the block's range on its sort axis
           const uint32_t bhi = some ? (uint32_t) (cz - lx0) >> sh : 0u, blo = some ? (uint32_t) (ca - lx0) >> sh : 0u;
-          const uint32_t hi = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (bhi >> 2) << 2, (int) tab.x) >> ((bhi & 3u) * 8u)) & 0xFFu;
-          const uint32_t lo = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (blo >> 2) << 2, (int) tab.y) >> ((blo & 3u) * 8u)) & 0xFFu;
+          const uint32_t hi = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (bhi >> 2) << 2, (int) tab.x) >> ((bhi & 3u) * 8u)) & 0x7Fu;
+          const uint32_t lo = ((uint32_t) __builtin_amdgcn_ds_bpermute((int) (blo >> 2) << 2, (int) tab.y) >> ((blo & 3u) * 8u)) & 0x7Fu;
           int j = some ? (int) hi - 1 : -1;
           const int jlo = some ? (int) lo : 0;
           while (__ballot(j >= jlo)) {
@@ -1538,7 +1560,9 @@ __device__ __forceinline__ void pip_locate(const PipArgs& A, const uint32_t bid,
         if (STATS) st_leaf++;
         // (lanes whose ray cannot use this block any more, or never could, sit the visit out: `want`)
         const int32_t qbest_before = qbest;
-        const int ub = wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
+        // (a block sorted by y -- k_build_leaves: maps whose PIP query runs on the column index and comes here for its
+        //  overflowed lists only -- has no x order to search; its prefix maxima all read "never ends" and every slot is tested)
+        const int ub = bcast(pm, 0) == 0x7FFFFFFF ? 64 : wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
         int j = want ? ub - 1 : -1;
         const int cnt_before = cnt;
         if (STATS) st_leaf_lanes += (unsigned long long) __popcll(__ballot(want));
@@ -1786,8 +1810,8 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
         const uint32_t bk = want ? ((uint32_t) qx - sx0s) >> sh : 0u;
         const uint32_t bsh = (bk & 3u) * 8u;
-        const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
-        const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+        const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
+        const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
         // One correction per end (both fetches in one round trip): the range is exact to a bucket, and with ~28 lanes
         // looking, some lane's bucket nearly always holds a vertex -- a slot that starts behind the point, or one
         // that ends before it -- which would cost the whole wave an iteration each.
@@ -1798,6 +1822,9 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
           j -= top_x0 > qx ? 1 : 0;
           jlo += low_x1 < qx ? 1 : 0;  // (slots below lo end before the bucket, so slot lo's prefix max is its own x1)
         }
+        // (a block sorted by y -- k_build_leaves: only on maps whose PIP query has a column index, i.e. not this kernel's
+        //  daily work -- has no x order: every slot is tested)
+        if (leaf_ysort(tab)) { j = 63; jlo = 0; }
         j = want ? j : -1;
         jlo = want ? jlo : 0;
         const int32_t qbest_before = qbest;
@@ -2107,6 +2134,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         if (STATS && cyc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RJ_CK(ck_leaf_wait, ck); }
         const uint32_t sx0s = __builtin_amdgcn_readfirstlane((uint32_t) ex0);
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
+        const bool ysort = leaf_ysort(tab);
         bool changed = false;
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -2117,8 +2145,8 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
           //  the block or its bound below the block: two selects less per visit)
           const uint32_t bk = ((uint32_t) qx[p] - sx0s) >> sh;
           const uint32_t bsh = (bk & 3u) * 8u;
-          const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
-          const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+          const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
+          const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
           int j = (int) hi - 1, jlo = (int) lo;
           {
             const int32_t top_x0 = __builtin_amdgcn_ds_bpermute(j << 2, bb.x0);
@@ -2126,6 +2154,7 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
             j -= top_x0 > qx[p] ? 1 : 0;
             jlo += low_x1 < qx[p] ? 1 : 0;
           }
+          if (ysort) { j = 63; jlo = 0; }  // (a block sorted by y has no x order: every slot is tested -- see k_pip_walk)
           j = want[p] ? j : -1;
           const int32_t qbest_before = qbest[p];
           auto scan_step = [&]() {
@@ -2508,9 +2537,10 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
                                const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* run_len, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ) {
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, bool allow_ysort) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
-                     left, right, ne, piece_begin, piece_len, run_first, run_len, leaf_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ);
+                     left, right, ne, piece_begin, piece_len, run_first, run_len, leaf_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ,
+                     allow_ysort ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -2618,12 +2648,12 @@ hipError_t launch_group_extent_tail(hipStream_t st, const int64_t* pts, const ui
 }
 
 hipError_t launch_query_keys(hipStream_t st, bool points, const int64_t* pts, const Seg* segs, uint64_t begin,
-                             uint64_t n, MortonKey* keys, uint32_t* vals) {
+                             uint64_t n, MortonKey* keys, uint32_t* vals, int strip_shift) {
   if (n == 0) return hipSuccess;
   if (points)
-    hipLaunchKernelGGL(k_query_keys<true>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals);
+    hipLaunchKernelGGL(k_query_keys<true>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals, strip_shift);
   else
-    hipLaunchKernelGGL(k_query_keys<false>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals);
+    hipLaunchKernelGGL(k_query_keys<false>, dim3(grid_for(n, 256, 8192)), dim3(256), 0, st, pts, segs, begin, n, keys, vals, 0);
   return hipGetLastError();
 }
 

@@ -110,3 +110,48 @@ def test_short_rings_share_leaves(oracle):
                 assert np.array_equal(face, om[0].face_ids(want_e)), (what, solo, spread)
         finally:
             h.close()
+
+
+@pytest.mark.parametrize("shape", ["long", "short_rows", "rings"])
+def test_blocks_sorted_by_y_change_no_result(oracle, shape):
+    """Round 6, "leaf_ysort": a leaf block taller than wide ordered by y0 (bucket table on y) -- what a query SEGMENT's scan
+    wants of a steep run -- instead of x0.  Forced on every map here (by default only where the PIP query has a column
+    index and never touches the leaves): LSI through both kernels (one and two segments per lane), the PIP walks (one and two
+    points per lane) and k_pip alone, which all test every slot of such a block, against the oracle and against the x-sorted
+    index; both map roles; and the plan says what the build did."""
+    if shape == "long":
+        g = [synth.lattice_map(7, 150, 31), synth.lattice_map(16, 70, 32)]
+    elif shape == "short_rows":  # 9- and 7-edge chains stitched into rows and columns: the steep ones fold back and forth in x
+        g = [synth.lattice_map(34, 9, 33), synth.lattice_map(30, 7, 34)]
+    else:
+        g = [synth.ring_map(2500, 30000, 35), synth.lattice_map(40, 12, 36)]
+    ctx = maps.Context(g).load()
+    m = ctx.maps
+    om = [_omap(oracle, m[0]), _omap(oracle, m[1])]
+    want_pairs = oracle.lsi_grid(om[0], om[1], 256)["eid"]
+    h = _capi.Handle(0)
+    try:
+        for i in (0, 1):
+            h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
+        h.set_option("pip_columns", 0)   # (the tree kernels are what is under test)
+        for ysort in (1, 0):
+            h.set_option("leaf_ysort", ysort)
+            for base in (0, 1):
+                q = m[1 - base]
+                want_e = oracle.pip_grid(om[base], base, q.pts, 256)
+                for lsi_segments, walk_points, pip_walk in ((2, 2, 1), (1, 1, 1), (2, 2, 0)):
+                    h.set_option("lsi_segments", lsi_segments)
+                    h.set_option("pip_walk_points", walk_points)
+                    h.set_option("pip_walk", pip_walk)
+                    pairs, closest, face = _run(h, base, q, 8 * len(want_pairs) + 1024)
+                    assert h.get_option("leaf_ysort_used%d" % base) == ysort
+                    assert h.get_plan()["index"][base]["steep_blocks_sorted_by_y"] is bool(ysort)
+                    assert np.array_equal(pairs, want_pairs), (shape, ysort, base, lsi_segments)
+                    assert np.array_equal(closest, want_e), (shape, ysort, base, walk_points, pip_walk)
+                    assert np.array_equal(face, om[base].face_ids(want_e)), (shape, ysort, base, walk_points, pip_walk)
+        # the default: with the column index of a map of rings / short chains, without it on long chains
+        h.set_option("pip_columns", -1); h.set_option("leaf_ysort", -1); h.set_option("pip_walk", 1)
+        h.build_lbvh(0)
+        assert h.get_option("leaf_ysort_used0") == (0 if shape == "long" else 1) == h.get_option("pip_columns_used0")
+    finally:
+        h.close()

@@ -85,6 +85,20 @@ def test_plan_says_why_the_first_pass_differs():
     h.pip_query(0, 1, None, 0, q.n_points, closest, None)
     p = h.get_plan()
     assert p["index"][0]["columns"] and p["pip"]["first_pass"]["kernel"] == "k_pip_strip" and "column index" in p["pip"]["why"]
+    assert "closed rings" in p["index"][0]["columns_why"]
+    # round 6, the measured rule: a lattice of SHORT chains (mean below 16 edges) gets the column index too, one of long chains
+    # does not, and the plan says on what grounds either way
+    for k, want in ((9, True), (40, False)):
+        s = maps.Context([synth.lattice_map(50, k, 83), g1]).load().maps[0]
+        h.upload_map(0, s.pts, s.row_index, s.left, s.right)
+        h.build_lbvh(0)
+        h.pip_query(0, 1, None, 0, q.n_points, closest, None)
+        p = h.get_plan()
+        ix = p["index"][0]
+        assert ix["columns"] is want and abs(ix["mean_chain_edges"] - k) < 0.01 and ("short chains" in ix["columns_why"]) is want, ix
+        assert p["pip"]["first_pass"]["kernel"].startswith("k_pip_strip" if want else "k_pip_walk"), p["pip"]   # (a small query set walks one point per lane)
+    h.upload_map(0, b.pts, b.row_index, b.left, b.right)
+    h.build_lbvh(0)
     h.set_option("pip_walk", 0)
     h.pip_query(0, 1, None, 0, q.n_points, closest, None)
     p = h.get_plan()

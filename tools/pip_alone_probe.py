@@ -11,6 +11,7 @@ ap.add_argument("--base", default="WaterBodiesLike"); ap.add_argument("--query",
 ap.add_argument("--columns", type=int, default=None, help="rj_set_option pip_columns before the build (1: force the column index)")
 ap.add_argument("--strip-shift", type=int, default=0, help="debug option strip_shift for the build (0: by the map)")
 ap.add_argument("--query-order", type=int, default=None, help="rj_set_option query_order (2: always through the Morton permutation)")
+ap.add_argument("--strip-major", type=int, default=0, help="debug option query_key_strips: a re-ordered set over a column index is sorted strip-major")
 a = ap.parse_args()
 ctx = maps.Context([synth.standin(a.base), synth.standin(a.query)]).load()
 b, q = ctx.maps
@@ -23,6 +24,8 @@ if a.strip_shift:
 h.build_lbvh(0)
 if a.query_order is not None:
     h.set_option("query_order", a.query_order)
+if a.strip_major:
+    h.set_debug_option("query_key_strips", 1)
 closest = h.alloc(4 * q.n_points); faces = h.alloc(4 * q.n_points)
 w, k = [], []
 for _ in range(a.reps):
@@ -30,5 +33,5 @@ for _ in range(a.reps):
     w.append(h.last_ms(_capi.RJ_T_PIP_WALK)); k.append(h.last_ms(_capi.RJ_T_PIP_KERNEL))
 e = closest.to_host(np.uint32)[:q.n_points]
 order_ms = h.last_ms(_capi.RJ_T_ORDER) if a.query_order == 2 else None
-print(json.dumps({"strip_shift": h.get_option("pip_column_shift0"), "entries": h.get_option("pip_column_entries0"), "order_ms_last": order_ms, "ordered": h.get_option("query_last_ordered"), "lib": os.environ.get("RAYJOIN_AMD_LIB", "tree"), "pair": a.base + " x " + a.query, "first_pass_ms": round(float(np.median(w[2:])), 4),
+print(json.dumps({"strip_major": a.strip_major, "query_order": a.query_order, "strip_shift": h.get_option("pip_column_shift0"), "entries": h.get_option("pip_column_entries0"), "order_ms_last": order_ms, "ordered": h.get_option("query_last_ordered"), "lib": os.environ.get("RAYJOIN_AMD_LIB", "tree"), "pair": a.base + " x " + a.query, "first_pass_ms": round(float(np.median(w[2:])), 4),
                   "query_ms": round(float(np.median(k[2:])), 4), "hits": int((e != 0xFFFFFFFF).sum()), "eid_sum": int(e[e != 0xFFFFFFFF].astype(np.uint64).sum())}))
