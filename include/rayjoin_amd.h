@@ -310,12 +310,12 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  *                                             chains are SHORT (mean below 16 edges: fat leaves; measured rule, round 6),
  *                                             0 never, 1 always.  rj_get_plan's index[].columns_why says which applied.
  *                                             (Environment RJ_PIP_COLUMNS=0/1 changes the default: A/B runs.)
- * "leaf_ysort"       -1 / 0 / 1               the order inside a leaf block on the NEXT rj_build_lbvh.  Blocks are sorted by x0 with
- *                                             a bucket table on x (what an upward ray needs).  1: a block TALLER than wide is
- *                                             sorted by y0 instead, table on y -- a query segment then scans the slots over its
- *                                             y-range (steep runs of polylines stitched from short chains fold back and forth in
- *                                             x); the PIP traversals test every slot of such a block.  -1: where the same build
- *                                             makes a column index ("pip_columns"), i.e. the leaves serve LSI alone.  0 never.
+ * "leaf_ysort"       1 / 0                    the order inside a leaf block on the NEXT rj_build_lbvh.  Blocks lie sorted by x0 with
+ *                                             a bucket table on x (what an upward ray needs).  1: a block TALLER than wide also gets
+ *                                             a SECOND order, by y0, with its own table -- a query segment then scans the slots over
+ *                                             its y-range (a steep run of a polyline folds back and forth in x: most of its edges lie
+ *                                             over every query's x-range); the PIP traversals keep the x order.  8 bytes per slot.
+ *                                             0: x order only.  (Environment RJ_LEAF_YSORT=0 changes the default: A/B runs.)
  * "pip_walk"         1 / 0 / 2                a PIP query = k_pip_walk* (integer-only traversal) + k_pip_exact (exact
  *                                             predicate over the candidate lists; its first blocks locate the points
  *                                             whose list overflowed).  1: unless the last query of this size left > 30 %

@@ -56,6 +56,7 @@ struct BvhState {
   QBox* box0 = nullptr;
   int32_t* pmx1 = nullptr;
   uint2* xtab = nullptr;
+  uint2* ytab2 = nullptr;   // the second order of blocks taller than wide (k_build_leaves; "leaf_ysort")
   uint32_t* occ = nullptr;
   uint32_t* sky = nullptr;  // skyline of the map (rj_device.h kSkyShift): what the PIP kernels prove a miss with
   bool use_sky = false;     // ... filled and used (maps of isolated rings)
@@ -255,7 +256,7 @@ struct rj_handle_s {
   size_t strip_scratch_bytes = 0;
   int pip_columns = -1;      // "pip_columns": -1 auto (maps of closed rings or of short chains), 0 never, 1 always -- the column index of the NEXT rj_build_lbvh
   int last_columns = 0;      // the last PIP query's first pass ran on the column index
-  int leaf_ysort = -1;       // "leaf_ysort": -1 auto (where the NEXT rj_build_lbvh also builds a column index: the leaves serve LSI only), 0 never, 1 always -- blocks taller than wide are ordered by y
+  int leaf_ysort = 1;        // "leaf_ysort": 1 (default) the NEXT rj_build_lbvh gives blocks taller than wide a second order, by y, for the LSI kernels; 0: x order only
   int skyline = -1;          // "skyline": -1 auto (maps of isolated rings), 0 never, 1 always -- what the NEXT rj_build_lbvh does
   int max_blocks = 1 << 20;  // cap on the persistent grid (default: whatever is resident)
   int chunk_groups = 0;      // consecutive groups handed to a wave at a time; 0 = per kernel (k_lsi 8, k_pip 6: measured optima; k_pip's waves share a chunk's rest inside the block)
@@ -358,7 +359,7 @@ void free_bvh(BvhState& b) {
   if (b.pool) {
     (void) hipFree(b.pool);  // (sseg ... sky and the levels are carved out of it)
   } else {
-    (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.occ); (void) hipFree(b.sky);
+    (void) hipFree(b.sseg); (void) hipFree(b.seid); (void) hipFree(b.sface); (void) hipFree(b.box0); (void) hipFree(b.pmx1); (void) hipFree(b.xtab); (void) hipFree(b.ytab2); (void) hipFree(b.occ); (void) hipFree(b.sky);
     for (int l = 0; l < kMaxLevels; l++) (void) hipFree(b.lvl[l]);
   }
   (void) hipFree(b.strip_ytab); (void) hipFree(b.strip_info); (void) hipFree(b.strip_tall); (void) hipFree(b.strip_box);
@@ -367,7 +368,7 @@ void free_bvh(BvhState& b) {
 
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
-  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.occ = b.occ; d.sky = b.use_sky ? b.sky : nullptr;
+  d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.ytab2 = b.ysort ? b.ytab2 : nullptr; d.occ = b.occ; d.sky = b.use_sky ? b.sky : nullptr;
   for (int l = 0; l < kMaxLevels; l++) {
     d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l];
     d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
@@ -519,7 +520,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (const char* e = getenv("RJ_LSI_SEGMENTS")) h->lsi_segments = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
   if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : (atoi(e) == 4 ? 4 : 2);  // (A/B runs)
   if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
-  if (const char* e = getenv("RJ_LEAF_YSORT")) { const int v = atoi(e); h->leaf_ysort = v < -1 || v > 1 ? -1 : v; }      // (A/B runs)
+  if (const char* e = getenv("RJ_LEAF_YSORT")) h->leaf_ysort = atoi(e) == 0 ? 0 : 1;                                    // (A/B runs)
   if (const char* e = getenv("RJ_PIP_COLUMNS")) { const int v = atoi(e); h->pip_columns = v < -1 || v > 1 ? -1 : v; }    // (A/B runs: the column index on / off whatever the map)
   {
     hipDeviceProp_t prop;
@@ -810,7 +811,7 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     return RJ_OK;
   }
   if (!strcmp(name, "leaf_ysort")) {
-    if (value < -1 || value > 1) return fail(h, RJ_E_INVALID, "leaf_ysort: -1 auto (maps that get a column index), 0 never, 1 always");
+    if (value < 0 || value > 1) return fail(h, RJ_E_INVALID, "leaf_ysort: 1 blocks taller than wide get a second order by y (LSI), 0 x order only");
     h->leaf_ysort = (int) value;
     return RJ_OK;
   }
@@ -1297,7 +1298,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     size_t used = 0;
     auto take = [&](size_t bytes) { const size_t at = used; used = (used + bytes + 255) & ~(size_t) 255; return at; };
     const size_t o_sseg = take(sizeof(Seg) * b.n0p), o_seid = take(4 * b.n0p), o_sface = take(4 * b.n0p), o_box0 = take(sizeof(QBox) * b.n0p),
-                 o_pmx1 = take(4 * b.n0p), o_xtab = take(sizeof(uint2) * b.n0p), o_occ = take(4 * ((size_t) kOccDim * kOccRowWords + 1)),
+                 o_pmx1 = take(4 * b.n0p), o_xtab = take(sizeof(uint2) * b.n0p), o_ytab2 = take(sizeof(uint2) * b.n0p), o_occ = take(4 * ((size_t) kOccDim * kOccRowWords + 1)),
                  o_sky = take(4 * ((size_t) kSkyBuckets + 1));  // (the skyline's 1 MiB: allocated with the index, filled when wanted)
     size_t o_lvl[kMaxLevels] = {0};
     for (int l = 1; l <= top; l++) o_lvl[l] = take(sizeof(QBox) * (b.alloc[l] + b.alloc[l] / 2));  // 16 B box + 8 B order word per node
@@ -1308,7 +1309,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
         return fail(h, pe == hipErrorOutOfMemory ? RJ_E_NOMEM : RJ_E_HIP, "rj_build_lbvh: hipMalloc of %zu bytes for the index failed: %s", used, hipGetErrorString(pe));
       }
       b.sseg = (Seg*) (b.pool + o_sseg); b.seid = (uint32_t*) (b.pool + o_seid); b.sface = (int32_t*) (b.pool + o_sface);
-      b.box0 = (QBox*) (b.pool + o_box0); b.pmx1 = (int32_t*) (b.pool + o_pmx1); b.xtab = (uint2*) (b.pool + o_xtab);
+      b.box0 = (QBox*) (b.pool + o_box0); b.pmx1 = (int32_t*) (b.pool + o_pmx1); b.xtab = (uint2*) (b.pool + o_xtab); b.ytab2 = (uint2*) (b.pool + o_ytab2);
       b.occ = (uint32_t*) (b.pool + o_occ); b.sky = (uint32_t*) (b.pool + o_sky);
       for (int l = 1; l <= top; l++) b.lvl[l] = (QBox*) (b.pool + o_lvl[l]);
     } else {
@@ -1319,6 +1320,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
       if (!r) r = dev_alloc(h, &b.box0, b.n0p);
       if (!r) r = dev_alloc(h, &b.pmx1, b.n0p);
       if (!r) r = dev_alloc(h, &b.xtab, b.n0p);
+      if (!r) r = dev_alloc(h, &b.ytab2, b.n0p);
       if (!r) r = dev_alloc(h, &b.occ, (uint64_t) kOccDim * kOccRowWords + 1);
       if (!r) r = dev_alloc(h, &b.sky, (uint64_t) kSkyBuckets + 1);
       for (int l = 1; l <= top && !r; l++) r = dev_alloc(h, &b.lvl[l], b.alloc[l] + b.alloc[l] / 2);
@@ -1353,15 +1355,10 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     // stand-in, 240 leaf blocks opened for each).  So: built where most chains are closed rings.
     // (filled below: by the column index's own pass where the map gets one, else by a pass over the leaves' boxes)
     b.use_sky = false;
-    {
-      // (the blocks' sort axis: y for steep blocks where the PIP query will run on the column index built below and the
-      //  leaves serve LSI alone -- "leaf_ysort", k_build_leaves)
-      const bool columns_coming = h->pip_columns == 1 || (h->pip_columns < 0 && m.runs_cut && m.nc && (2 * m.closed_chains >= m.nc || m.ne / m.nc < 16));
-      b.ysort = h->leaf_ysort == 1 || (h->leaf_ysort < 0 && columns_coming);
-    }
+    b.ysort = h->leaf_ysort != 0;  // ("leaf_ysort": blocks taller than wide get a second order, by y, for the LSI kernels)
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, nruns ? m.piece_begin : nullptr,
                                  m.piece_len, m.run_first, m.run_len, m.leaf_first, b.n0p / 64, b.alloc[1],
-                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ, b.ysort)) != hipSuccess) break;
+                                 b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ, b.ysort ? b.ytab2 : nullptr)) != hipSuccess) break;
     toc(h, RJ_T_BUILD_LEAVES);
     tic(h, RJ_T_BUILD_LEVELS);
     const QBox* child = b.lvl[1];

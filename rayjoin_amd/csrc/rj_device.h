@@ -114,6 +114,7 @@ struct DeviceBvh {
                           // .x byte k = slots of the block whose x0 lies in a bucket <= 4l+k (the scan of a point in that
                           // bucket starts below this slot), .y byte k = slots whose prefix-max x1 ends before the bucket
                           // (where the scan stops): the candidates of a point, without a search and without a stop test
+  const uint2* ytab2;     // [n0p] the same table on y over the order by y0, for blocks taller than wide (LSI only; nullable) -- leaf_is_steep
   const uint32_t* occ;    // occupancy bitmap, kOccDim x kOccDim cells (bit set = some segment box touches the cell)
   const uint32_t* sky;    // skyline, kSkyBuckets + 1 words (see kSkyShift); nullable
   DeviceStrips strips;    // column index (ytab == nullptr: none)
@@ -134,12 +135,24 @@ __host__ __device__ __forceinline__ int leaf_bucket_shift(uint32_t extent_minus_
   if (extent_minus_1 < 256u) return 0;
   return 24 - __builtin_clz(extent_minus_1);  // (extent_minus_1 >> shift) < 256
 }
-// A leaf block's SORT AXIS (k_build_leaves): blocks are ordered by x0 (prefix max of x1, bucket table on x) -- or, where the
-// map's PIP query has a column index and the block is taller than wide, by y0 (prefix max of y1, table on y).  The flag is
-// the one spare bit of the table: bit 31 of lane 63's second word (the counts there are <= 64).
-constexpr uint32_t kLeafYSortBit = 0x80000000u;
-__device__ __forceinline__ bool leaf_ysort(const uint2& tab_of_this_lane) {
-  return ((uint32_t) __builtin_amdgcn_readlane((int) tab_of_this_lane.y, 63) & kLeafYSortBit) != 0u;
+// A leaf block's SECOND order (k_build_leaves, round 6): blocks lie in x order (x0 ascending, prefix max of x1, bucket table on
+// x: xtab).  A block TALLER than wide -- by its level-1 box, so whoever pushes it can tell -- also has ytab2: the same table on
+// y over the order by y0, for the LSI kernels only; the x-order slot of y-rank `lane` sits in the table's spare bits (every
+// count is <= 64: bit 7 of the four bytes of .x and of the low two bytes of .y).
+// (taller than 1.25 x its width: a step of the y order costs one cross-lane read more than one of the x order, and a block
+//  of packed rings -- about as tall as wide -- gains nothing from it: measured +4 % on k_lsi2 over the lake-shaped base map)
+__host__ __device__ __forceinline__ bool leaf_is_steep(int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
+  const uint32_t w = (uint32_t) (x1 - x0), h = (uint32_t) (y1 - y0);
+  return h > w && h - w > (w >> 2);
+}
+__device__ __forceinline__ uint32_t leaf_perm_bits_lo(uint32_t slot) {  // bits 0..3 of the slot -> bit 7 of bytes 0..3
+  return ((slot & 1u) << 7) | ((slot & 2u) << 14) | ((slot & 4u) << 21) | ((slot & 8u) << 28);
+}
+__device__ __forceinline__ uint32_t leaf_perm_bits_hi(uint32_t slot) {  // bits 4, 5 -> bit 7 of bytes 0, 1
+  return ((slot & 16u) << 3) | ((slot & 32u) << 10);
+}
+__device__ __forceinline__ uint32_t leaf_perm_of(const uint2& tab) {
+  return ((tab.x >> 7) & 1u) | ((tab.x >> 14) & 2u) | ((tab.x >> 21) & 4u) | ((tab.x >> 28) & 8u) | ((tab.y >> 3) & 16u) | ((tab.y >> 10) & 32u);
 }
 __device__ __forceinline__ const uint64_t* sibling_order(const DeviceBvh& T, int l) {
   return T.ord[l];  // (= lvl[l] + pad64(nlvl[l]): one scalar load instead of a dozen scalar instructions per node expansion)

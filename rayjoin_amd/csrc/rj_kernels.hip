@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                                       Seg* __restrict__ sseg, uint32_t* __restrict__ seid,
                                                       int32_t* __restrict__ sface, QBox* __restrict__ box0,
                                                       int32_t* __restrict__ pmx1, uint2* __restrict__ xtab,
-                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ, int allow_ysort) {
+                                                      QBox* __restrict__ lvl1, uint32_t* __restrict__ occ, uint2* __restrict__ ytab2) {
   __shared__ int32_t sx1[4][64];
   __shared__ uint4 hist[4][64];  // 256 x-bucket counters per wave
   const int lane = lane_id();
@@ -408,52 +408,40 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
     }
     mark_occupancy_wave(b, valid, occ, lane);
     const int32_t ux0 = wave_min(b.x0), uy0 = wave_min(b.y0), ux1 = wave_max(b.x1), uy1 = wave_max(b.y1);
-    // The block's SORT AXIS (round 6).  x where upward rays use the block (every map without a column index): a point's
-    // candidates are the slots over its x.  Where the PIP query has a column index instead (allow_ysort: maps of closed rings
-    // or of short chains) the block only serves LSI, and a block that is TALLER than wide -- a steep run of a polyline stitched
-    // from short chains folds back and forth in x, every edge over every query's x-range -- is ordered by y0 instead, prefix
-    // max and bucket table on y: a query segment's scan is the slots over its Y-range.  Flagged in the one spare bit of the
-    // table (bit 31 of lane 63's second word: counts are <= 64); the PIP traversals scan such a block whole.
-    const bool ysort = allow_ysort && (uint32_t) (uy1 - uy0) > (uint32_t) (ux1 - ux0);
-    const int32_t a0 = ysort ? b.y0 : b.x0, a1 = ysort ? b.y1 : b.x1;
-    const int32_t ua0 = ysort ? uy0 : ux0, ua1 = ysort ? uy1 : ux1;
-    int rank = 0;
-    for (int k = 0; k < 64; k++) {
-      const int32_t xk = bcast(a0, k);
-      rank += (xk < a0 || (xk == a0 && k < lane)) ? 1 : 0;
-    }
-    const uint64_t o = blk * 64 + rank;
-    sseg[o] = s;
-    seid[o] = id;
-    sface[o] = fc;
-    box0[o] = b;
-    sx1[wib][rank] = a1;
-    wave_lds_fence();
-    int32_t m = sx1[wib][lane];
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int32_t t = __shfl_up(m, d, 64);
-      if (lane >= d) m = t > m ? t : m;
-    }
-    pmx1[blk * 64 + lane] = ysort ? 0x7FFFFFFF : m;  // (read by k_pip's locate only, which needs the x order: "never ends" = test every slot)
-    wave_lds_fence();
     if (lane == 0) lvl1[blk] = QBox{ux0, uy0, ux1, uy1};
-    // x-bucket table (k_pip_walk): 256 buckets over the block's x-extent.  The block is x0-sorted, so the segments
-    // that can contain a point of bucket b in x are the slots [lo_b, hi_b): hi_b = how many segments START in a
-    // bucket <= b, lo_b = how many have a prefix-max x1 that ENDS before bucket b (the prefix max is monotone, so
-    // those are the first slots).  Two histograms + two prefix sums; the point's scan needs no search for its
-    // first slot and no prefix-max fetch to know its last.
-    {
+    // The block's order: by x0, with the prefix max of x1 and a 256-bucket table on x -- what an upward ray needs (the
+    // slots over its x) and what a query SEGMENT needs of a block that is wider than tall (the slots over its x-range).
+    // Round 6: a block TALLER than wide -- a steep run of a polyline: its edges fold back and forth in x, most of them lie
+    // over every query's x-range -- gets a SECOND order for the segment queries: by y0, table on y (ytab2), the slots of
+    // that order packed into the table's spare bits (the counts are <= 64: bit 7 of six of a lane's eight bytes hold the
+    // x-order slot of y-rank `lane`).  The block itself stays in x order: the PIP traversals never see the difference.
+    // One pass per axis: rank by a0 (ties by lane), prefix max of a1 along that order, two histograms + two prefix sums:
+    //   hi_b = how many slots START in a bucket <= b, lo_b = how many have a prefix max that ENDS before bucket b.
+    auto order_on = [&](const int32_t a0, const int32_t a1, const int32_t ua0, const int32_t ua1, int& rank, int32_t& pmax, uint32_t (&packed)[2]) {
+      rank = 0;
+      for (int k = 0; k < 64; k++) {
+        const int32_t xk = bcast(a0, k);
+        rank += (xk < a0 || (xk == a0 && k < lane)) ? 1 : 0;
+      }
+      sx1[wib][rank] = a1;
+      wave_lds_fence();
+      int32_t m = sx1[wib][lane];
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        int32_t t = __shfl_up(m, d, 64);
+        if (lane >= d) m = t > m ? t : m;
+      }
+      pmax = m;
+      wave_lds_fence();
       const int sh = leaf_bucket_shift((uint32_t) (ua1 - ua0));
       const int nvalid = __popcll(__ballot(valid));
       uint32_t* hw = reinterpret_cast<uint32_t*>(&hist[wib][0]);
-      uint32_t packed[2];
 #pragma unroll
       for (int pass = 0; pass < 2; pass++) {
         hist[wib][lane] = make_uint4(0, 0, 0, 0);
         wave_lds_fence();
-        // pass 0: by the bucket of x0 (this lane's own segment); pass 1: by the bucket of the prefix max of slot `lane`
-        // (padding slots sort last and count in neither: a point never scans them)
+        // pass 0: by the bucket of a0 (this lane's own segment); pass 1: by the bucket of the prefix max of slot `lane`
+        // (padding slots sort last and count in neither: a query never scans them)
         const bool use = pass == 0 ? valid : lane < nvalid;
         const int32_t v = pass == 0 ? a0 : m;
         if (use) atomicAdd(&hw[(uint32_t) (v - ua0) >> sh], 1u);
@@ -472,8 +460,28 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
                                  : exc | ((exc + p0) << 8) | ((exc + p1) << 16) | ((exc + p2) << 24);
         wave_lds_fence();
       }
-      xtab[blk * 64 + lane] = make_uint2(packed[0], packed[1] | ((ysort && lane == 63) ? kLeafYSortBit : 0u));
+    };
+    int rank = 0;
+    int32_t m = 0;
+    uint32_t packed[2];
+    order_on(b.x0, b.x1, ux0, ux1, rank, m, packed);
+    const uint64_t o = blk * 64 + rank;
+    sseg[o] = s;
+    seid[o] = id;
+    sface[o] = fc;
+    box0[o] = b;
+    pmx1[blk * 64 + lane] = m;
+    xtab[blk * 64 + lane] = make_uint2(packed[0], packed[1]);
+    if (ytab2 && leaf_is_steep(ux0, uy0, ux1, uy1)) {
+      int ranky = 0;
+      int32_t my = 0;
+      uint32_t py[2];
+      order_on(b.y0, b.y1, uy0, uy1, ranky, my, py);
+      sx1[wib][ranky] = rank;  // the x-order slot of y-rank `ranky`
       wave_lds_fence();
+      const uint32_t xs = (uint32_t) sx1[wib][lane];
+      wave_lds_fence();
+      ytab2[blk * 64 + lane] = make_uint2(py[0] | leaf_perm_bits_lo(xs), py[1] | leaf_perm_bits_hi(xs));
     }
   }
 }
@@ -755,6 +763,13 @@ struct LsiWaveLds {
 };
 
 
+// a stack entry of the LSI traversals: level above the index; a level-1 child (a leaf block) that is taller than wide and has
+// its second order goes as level 0 -- the kernels then read its table on y (k_build_leaves, rj_device.h leaf_is_steep)
+__device__ __forceinline__ uint32_t lsi_entry(const DeviceBvh& T, int lvl, const QBox& b, uint32_t index) {
+  const bool by_y = lvl == 1 && T.ytab2 && leaf_is_steep(b.x0, b.y0, b.x1, b.y1);
+  return ((uint32_t) (by_y ? 0 : lvl) << 28) | index;
+}
+
 template <bool STATS>
 __device__ __forceinline__ void lsi_flush_hits(LsiWaveLds& L, int& nh, int n, const LsiArgs& A, int lane) {
   // write the top n (<= 64) hits of the wave's LDS buffer with ONE atomic
@@ -889,7 +904,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-      if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, T.top, b, (uint32_t) lane);
       sp = __popcll(m);
       wave_lds_fence();
     }
@@ -905,7 +920,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         // (cannot happen for a tree rj_build_lbvh accepted: kStackEntries covers the worst case, rj_device.h)
         if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, lvl - 1, b, idx * 64 + lane);
         sp += __popcll(m);
         if (STATS) st_nodes++;
         wave_lds_fence();
@@ -918,8 +933,9 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         // x-extent (what the table was built on) is re-derived from its boxes: padding slots are empty boxes.
         const uint32_t slot0 = idx * 64;
         if (STATS) st_leaf++;
-        // (the block's sort axis: x, or -- a steep block of a map whose PIP query has a column index -- y: k_build_leaves)
-        const bool ysort = leaf_ysort(tab);
+        // (the order the block is taken by: x, or -- a block taller than wide, pushed as level 0 -- its second one, y)
+        const bool ysort = lvl == 0;
+        const uint32_t yslot = leaf_perm_of(tab);  // (ysort: the x-order slot of y-rank `lane`)
         const int32_t lx0 = wave_min(ysort ? b.y0 : b.x0), lx1 = wave_max(ysort ? b.y1 : b.x1);
         const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
         const int32_t qa0 = ysort ? qy0 : qx0, qa1 = ysort ? qy1 : qx1;
@@ -931,7 +947,8 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         int j = some ? (int) hi - 1 : -1;
         const int jlo = some ? (int) lo : 0;
         while (__ballot(j >= jlo)) {
-          const int ja = j << 2;  // (ds_bpermute takes the lane from bits 7:2 of the address; a lane past its range reads some slot, harmlessly)
+          // (ds_bpermute takes the lane from bits 7:2 of the address; a lane past its range reads some slot, harmlessly)
+          const int ja = ysort ? __builtin_amdgcn_ds_bpermute(j << 2, (int) yslot) << 2 : j << 2;
           const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, b.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, b.x1);
           const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, b.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, b.y1);
           // box overlap and "still inside my range" as one sign test
@@ -939,7 +956,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
           const uint64_t cm = __ballot(c);
           if (STATS) st_box++;
           if (cm) {
-            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q, slot0 + (uint32_t) (j & 63));
+            if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q, slot0 + (uint32_t) ((ja >> 2) & 63));
             np += __popcll(cm);
             wave_lds_fence();
             if (np >= 64) lsi_drain<STATS>(L, np, nh, 64, A, lane, st_tests);
@@ -955,7 +972,8 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       // one address for both kinds of entry keeps the loads branch-free (the bucket table is only meaningful for leaves)
       const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
       b = src[c];
-      tab = T.xtab[lvl > 1 ? (uint64_t) lane : c];
+      const uint2* tsrc = lvl == 0 ? T.ytab2 : T.xtab;  // (level 0 = a leaf block taken by its y order: lsi_entry)
+      tab = tsrc[lvl > 1 ? (uint64_t) lane : c];
     };
     while (sp > 0) {
       const bool two = sp > 1;
@@ -1084,7 +1102,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-      if ((m >> lane) & 1) L.stack[rank_below(m)] = ((uint32_t) T.top << 28) | (uint32_t) lane;
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, T.top, b, (uint32_t) lane);
       sp = __popcll(m);
       wave_lds_fence();
     }
@@ -1094,12 +1112,13 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       if (lvl > 1) {
         uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = ((uint32_t) (lvl - 1) << 28) | (idx * 64 + lane);
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, lvl - 1, b, idx * 64 + lane);
         sp += __popcll(m);
         wave_lds_fence();
       } else {
         const uint32_t slot0 = idx * 64;
-        const bool ysort = leaf_ysort(tab);  // (the block's sort axis: k_build_leaves)
+        const bool ysort = lvl == 0;  // (the order the block is taken by: x, or -- taller than wide, pushed as level 0 -- y)
+        const uint32_t yslot = leaf_perm_of(tab);
         const int32_t lx0 = wave_min(ysort ? b.y0 : b.x0), lx1 = wave_max(ysort ? b.y1 : b.x1);
         const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
 #pragma unroll
@@ -1114,13 +1133,13 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
           int j = some ? (int) hi - 1 : -1;
           const int jlo = some ? (int) lo : 0;
           while (__ballot(j >= jlo)) {
-            const int ja = j << 2;
+            const int ja = ysort ? __builtin_amdgcn_ds_bpermute(j << 2, (int) yslot) << 2 : j << 2;
             const int32_t sx0 = __builtin_amdgcn_ds_bpermute(ja, b.x0), sx1 = __builtin_amdgcn_ds_bpermute(ja, b.x1);
             const int32_t sy0 = __builtin_amdgcn_ds_bpermute(ja, b.y0), sy1 = __builtin_amdgcn_ds_bpermute(ja, b.y1);
             const bool c = ((qx1[p] - sx0) | (sx1 - qx0[p]) | (qy1[p] - sy0) | (sy1 - qy0[p]) | (j - jlo)) >= 0;
             const uint64_t cm = __ballot(c);
             if (cm) {
-              if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q[p], slot0 + (uint32_t) (j & 63));
+              if (c) L.pairs[np + rank_below(cm)] = make_uint2((uint32_t) q[p], slot0 + (uint32_t) ((ja >> 2) & 63));
               np += __popcll(cm);
               wave_lds_fence();
               if (np >= 64) lsi_drain<false>(L, np, nh, 64, A, lane, st_tests);
@@ -1135,7 +1154,8 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       const uint64_t c = (uint64_t) (e & 0x0FFFFFFFu) * 64 + lane;
       const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
       b = src[c];
-      tab = T.xtab[lvl > 1 ? (uint64_t) lane : c];
+      const uint2* tsrc = lvl == 0 ? T.ytab2 : T.xtab;  // (level 0 = a leaf block taken by its y order: lsi_entry)
+      tab = tsrc[lvl > 1 ? (uint64_t) lane : c];
     };
     while (sp > 0) {
       const bool two = sp > 1;
@@ -1560,9 +1580,7 @@ __device__ __forceinline__ void pip_locate(const PipArgs& A, const uint32_t bid,
         if (STATS) st_leaf++;
         // (lanes whose ray cannot use this block any more, or never could, sit the visit out: `want`)
         const int32_t qbest_before = qbest;
-        // (a block sorted by y -- k_build_leaves: maps whose PIP query runs on the column index and comes here for its
-        //  overflowed lists only -- has no x order to search; its prefix maxima all read "never ends" and every slot is tested)
-        const int ub = bcast(pm, 0) == 0x7FFFFFFF ? 64 : wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
+        const int ub = wave_upper_bound(bb.x0, qx);  // (shuffles: executed by every lane)
         int j = want ? ub - 1 : -1;
         const int cnt_before = cnt;
         if (STATS) st_leaf_lanes += (unsigned long long) __popcll(__ballot(want));
@@ -1810,8 +1828,8 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
         const uint32_t bk = want ? ((uint32_t) qx - sx0s) >> sh : 0u;
         const uint32_t bsh = (bk & 3u) * 8u;
-        const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
-        const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
+        const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+        const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
         // One correction per end (both fetches in one round trip): the range is exact to a bucket, and with ~28 lanes
         // looking, some lane's bucket nearly always holds a vertex -- a slot that starts behind the point, or one
         // that ends before it -- which would cost the whole wave an iteration each.
@@ -1822,9 +1840,6 @@ __global__ __launch_bounds__(256, 8) void k_pip_walk(PipArgs A) {
           j -= top_x0 > qx ? 1 : 0;
           jlo += low_x1 < qx ? 1 : 0;  // (slots below lo end before the bucket, so slot lo's prefix max is its own x1)
         }
-        // (a block sorted by y -- k_build_leaves: only on maps whose PIP query has a column index, i.e. not this kernel's
-        //  daily work -- has no x order: every slot is tested)
-        if (leaf_ysort(tab)) { j = 63; jlo = 0; }
         j = want ? j : -1;
         jlo = want ? jlo : 0;
         const int32_t qbest_before = qbest;
@@ -2134,7 +2149,6 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
         if (STATS && cyc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); RJ_CK(ck_leaf_wait, ck); }
         const uint32_t sx0s = __builtin_amdgcn_readfirstlane((uint32_t) ex0);
         const int sh = leaf_bucket_shift(__builtin_amdgcn_readfirstlane((uint32_t) ex1) - sx0s);
-        const bool ysort = leaf_ysort(tab);
         bool changed = false;
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -2145,8 +2159,8 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
           //  the block or its bound below the block: two selects less per visit)
           const uint32_t bk = ((uint32_t) qx[p] - sx0s) >> sh;
           const uint32_t bsh = (bk & 3u) * 8u;
-          const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
-          const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0x7Fu;
+          const uint32_t hi = ((uint32_t) __shfl((int) tab.x, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
+          const uint32_t lo = ((uint32_t) __shfl((int) tab.y, (int) (bk >> 2), 64) >> bsh) & 0xFFu;
           int j = (int) hi - 1, jlo = (int) lo;
           {
             const int32_t top_x0 = __builtin_amdgcn_ds_bpermute(j << 2, bb.x0);
@@ -2154,7 +2168,6 @@ __device__ __forceinline__ void pip_walk_many(const PipArgs& A) {
             j -= top_x0 > qx[p] ? 1 : 0;
             jlo += low_x1 < qx[p] ? 1 : 0;
           }
-          if (ysort) { j = 63; jlo = 0; }  // (a block sorted by y has no x order: every slot is tested -- see k_pip_walk)
           j = want[p] ? j : -1;
           const int32_t qbest_before = qbest[p];
           auto scan_step = [&]() {
@@ -2537,10 +2550,10 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
                                const uint32_t* left, const uint32_t* right, uint64_t ne, const uint32_t* piece_begin,
                                const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* run_len, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
-                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, bool allow_ysort) {
+                               int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, uint2* ytab2) {
   hipLaunchKernelGGL(k_build_leaves, dim3(grid_for(n_parent_alloc, 4, 16384)), dim3(256), 0, st, seg, order, edge_chain,
                      left, right, ne, piece_begin, piece_len, run_first, run_len, leaf_first, nblocks, n_parent_alloc, sseg, seid, sface, box0, pmx1, xtab, lvl1, occ,
-                     allow_ysort ? 1 : 0);
+                     ytab2);
   return hipGetLastError();
 }
 

@@ -113,12 +113,11 @@ def test_short_rings_share_leaves(oracle):
 
 
 @pytest.mark.parametrize("shape", ["long", "short_rows", "rings"])
-def test_blocks_sorted_by_y_change_no_result(oracle, shape):
-    """Round 6, "leaf_ysort": a leaf block taller than wide ordered by y0 (bucket table on y) -- what a query SEGMENT's scan
-    wants of a steep run -- instead of x0.  Forced on every map here (by default only where the PIP query has a column
-    index and never touches the leaves): LSI through both kernels (one and two segments per lane), the PIP walks (one and two
-    points per lane) and k_pip alone, which all test every slot of such a block, against the oracle and against the x-sorted
-    index; both map roles; and the plan says what the build did."""
+def test_the_second_order_of_steep_blocks_changes_no_result(oracle, shape):
+    """Round 6, "leaf_ysort": a leaf block taller than wide gets a SECOND order, by y0 with a bucket table on y -- what a query
+    SEGMENT's scan wants of a steep run -- beside the x order the upward rays use.  On (the default) and off: LSI through both
+    kernels (one and two segments per lane) against the oracle, both map roles; the PIP kernels, which never see the second
+    order, likewise; and the plan says what the build did."""
     if shape == "long":
         g = [synth.lattice_map(7, 150, 31), synth.lattice_map(16, 70, 32)]
     elif shape == "short_rows":  # 9- and 7-edge chains stitched into rows and columns: the steep ones fold back and forth in x
@@ -131,9 +130,9 @@ def test_blocks_sorted_by_y_change_no_result(oracle, shape):
     want_pairs = oracle.lsi_grid(om[0], om[1], 256)["eid"]
     h = _capi.Handle(0)
     try:
+        assert h.get_option("leaf_ysort") == 1
         for i in (0, 1):
             h.upload_map(i, m[i].pts, m[i].row_index, m[i].left, m[i].right)
-        h.set_option("pip_columns", 0)   # (the tree kernels are what is under test)
         for ysort in (1, 0):
             h.set_option("leaf_ysort", ysort)
             for base in (0, 1):
@@ -149,9 +148,5 @@ def test_blocks_sorted_by_y_change_no_result(oracle, shape):
                     assert np.array_equal(pairs, want_pairs), (shape, ysort, base, lsi_segments)
                     assert np.array_equal(closest, want_e), (shape, ysort, base, walk_points, pip_walk)
                     assert np.array_equal(face, om[base].face_ids(want_e)), (shape, ysort, base, walk_points, pip_walk)
-        # the default: with the column index of a map of rings / short chains, without it on long chains
-        h.set_option("pip_columns", -1); h.set_option("leaf_ysort", -1); h.set_option("pip_walk", 1)
-        h.build_lbvh(0)
-        assert h.get_option("leaf_ysort_used0") == (0 if shape == "long" else 1) == h.get_option("pip_columns_used0")
     finally:
         h.close()
