@@ -1355,7 +1355,11 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     // stand-in, 240 leaf blocks opened for each).  So: built where most chains are closed rings.
     // (filled below: by the column index's own pass where the map gets one, else by a pass over the leaves' boxes)
     b.use_sky = false;
-    b.ysort = h->leaf_ysort != 0;  // ("leaf_ysort": blocks taller than wide get a second order, by y, for the LSI kernels)
+    // "leaf_ysort": blocks taller than wide get a second order, by y, for the LSI kernels -- where the leaves are runs of
+    // polylines.  Not on maps of closed rings: a block of packed rings is about as tall as wide, most of its edges lie over a
+    // query's range on either axis (8 scan steps per opened block whichever the order, tools/lsi_stats_probe.py), and a step of
+    // the y order costs one cross-lane read more: k_lsi2 + 3 % on the lake-shaped base map.
+    b.ysort = h->leaf_ysort != 0 && !(m.runs_cut && m.nc && 2 * m.closed_chains >= m.nc);
     if ((e = launch_build_leaves(h->stream, m.seg, v_out, m.edge_chain, m.left, m.right, m.ne, nruns ? m.piece_begin : nullptr,
                                  m.piece_len, m.run_first, m.run_len, m.leaf_first, b.n0p / 64, b.alloc[1],
                                  b.sseg, b.seid, b.sface, b.box0, b.pmx1, b.xtab, b.lvl[1], b.occ, b.ysort ? b.ytab2 : nullptr)) != hipSuccess) break;

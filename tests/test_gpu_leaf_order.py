@@ -143,8 +143,9 @@ def test_the_second_order_of_steep_blocks_changes_no_result(oracle, shape):
                     h.set_option("pip_walk_points", walk_points)
                     h.set_option("pip_walk", pip_walk)
                     pairs, closest, face = _run(h, base, q, 8 * len(want_pairs) + 1024)
-                    assert h.get_option("leaf_ysort_used%d" % base) == ysort
-                    assert h.get_plan()["index"][base]["steep_blocks_sorted_by_y"] is bool(ysort)
+                    used = ysort if not (shape == "rings" and base == 0) else 0   # (not on a map of closed rings: packed rings gain nothing)
+                    assert h.get_option("leaf_ysort_used%d" % base) == used
+                    assert h.get_plan()["index"][base]["steep_blocks_sorted_by_y"] is bool(used)
                     assert np.array_equal(pairs, want_pairs), (shape, ysort, base, lsi_segments)
                     assert np.array_equal(closest, want_e), (shape, ysort, base, walk_points, pip_walk)
                     assert np.array_equal(face, om[base].face_ids(want_e)), (shape, ysort, base, walk_points, pip_walk)
