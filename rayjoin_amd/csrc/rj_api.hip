@@ -120,6 +120,7 @@ struct rj_handle_s {
   bool co_points = false;     // ... and k_lsi_points ran between them
   uint64_t co_n = 0;          // query size the decision was made for (LSI segments)
   uint64_t co_np = 0;         // ... and the PIP side's (points)
+  uint64_t co_np_other = 0;   // a point count that differed from co_np once: the trials start again when it is seen a second time
   // how the chip is split when shared.  Both kernels are persistent, so what counts is what fits a CU together: the
   // register file takes 6 walk blocks + 2 k_lsi blocks, and that is where the step is shortest wherever the walk may keep
   // 8 blocks per CU (tree of <= 4 levels); where LDS limits it to 7 (5 levels) the best k_lsi grid is half a block per CU
@@ -178,6 +179,7 @@ struct rj_handle_s {
   int exact_buf = 0, exact_last = -1;       // the list set (1 + exact_buf) the next such query uses; the one the last used
   int exact_rot = 0;                        // ... and its rest-count word (kExactRestWord)
   bool exact_pending = false;               // something was enqueued on exact_stream since it was last joined
+  const void *exact_out_closest = nullptr, *exact_out_face = nullptr;  // the output arrays of the last query whose exact kernel went to exact_stream
   unsigned long long* h_rest = nullptr;    // mapped host words [0],[1]: the rest count of the last finished query per stream (a hint; [2]: see lsi_points_on_stream
   unsigned long long* d_rest = nullptr;    // for the next launch's grid and for "pip_rest"; the same memory as the device sees it)
   uint64_t walk_n[2] = {0, 0};             // size of the query the hint belongs to
@@ -412,7 +414,7 @@ hipError_t join_aux(rj_handle h) {
 // ---- "pip_concurrent" 2: which schedule for this pair? ------------------------------------------
 static void co_reset(rj_handle h) {
   h->plan.epoch++;  // (every decision taken so far is void: rj_get_plan)
-  h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0; h->co_np = 0;
+  h->co_trials = 0; h->co_best[0] = h->co_best[1] = h->co_best[2] = 1e30f; h->co_choice = -1; h->co_measure = false; h->co_n = 0; h->co_np = 0; h->co_np_other = 0;
   h->co_ratio = 0.46f;
   h->co_L = h->co_best_L = 0;
   h->co_best_imb = 0;
@@ -841,7 +843,7 @@ int rj_set_option(rj_handle h, const char* name, int64_t value) {
     RJ_HIP(h, hipStreamSynchronize(h->exact_stream));
     for (size_t wd : kExactRestWord) RJ_HIP(h, hipMemsetAsync(h->d_counter + wd, 0, 8, h->stream));
     RJ_HIP(h, hipStreamSynchronize(h->stream));
-    h->exact_rot = 0; h->exact_buf = 0; h->exact_last = -1;
+    h->exact_rot = 0; h->exact_buf = 0; h->exact_last = -1; h->exact_out_closest = h->exact_out_face = nullptr;
     h->exact_recorded[0] = h->exact_recorded[1] = false;
     h->exact_own_stream = (int) value;
     return RJ_OK;
@@ -1790,19 +1792,31 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     RJ_HIP(h, hipEventRecord(h->ev_order, h->stream));
     RJ_HIP(h, hipStreamWaitEvent(h->aux_stream, h->ev_order, 0));
   }
+  // (this pair's PIP share: derived NOW, from the split its LSI side -- already in flight -- was launched with; the reset below
+  //  clears what that split was derived from)
   const int max_blocks = aux && h->lsi_shared && h->pip_share_blocks() < h->max_blocks ? h->pip_share_blocks() : h->max_blocks;
+  const int walk_share_of_this_pair = h->lsi_share_blocks();
   // (auto mode: this PIP query completes a pair whose span the next pair's launch reads)
   h->co_measure = h->pip_concurrent == 2 && h->lsi_inflight && !(order && h->order_fresh) && !h->stats_on && n > 0;
   if (h->co_measure) {
     // (a pair with another point count is another workload: the schedule is decided again from the next pair on --
-    //  the pair in flight keeps the grids its LSI side was launched with)
+    //  the pair in flight keeps the grids its LSI side was launched with.  A size that differs ONCE -- the odd query of a
+    //  stream of equal ones -- does not start the trials again: only when the new size is seen a second time)
     if (h->co_np && (n > h->co_np + h->co_np / 4 || n + n / 4 < h->co_np)) {
-      const int keep_mode = h->co_mode;
-      co_reset(h);
-      h->co_mode = keep_mode;
       h->co_measure = false;  // (its span belongs to neither workload's trials)
+      if (h->co_np_other && !(n > h->co_np_other + h->co_np_other / 4 || n + n / 4 < h->co_np_other)) {
+        const int keep_mode = h->co_mode;
+        co_reset(h);
+        h->co_mode = keep_mode;
+        h->co_np = n;
+        h->co_np_other = 0;
+      } else {
+        h->co_np_other = n;
+      }
+    } else {
+      h->co_np = n;
+      h->co_np_other = 0;
     }
-    h->co_np = n;
   }
   hipStream_t st = aux ? h->aux_stream : h->stream;
   // each stream has its own scheduler block: a PIP on the aux stream and one on the main stream may be
@@ -1832,7 +1846,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
     // (k_lsi on up to two blocks per CU: the walk leaves exactly that room -- 6 + 2 resident blocks per CU, nothing
     //  waits for a slot; a larger LSI share: the walk keeps all but one, the LSI side's later blocks fill in as it drains.
     //  tools/share_probe.py on the headline pair: 512 + 1536 blocks 0.897 ms, 512 + 1792 0.907, 448 + 1792 0.917)
-    const int share = h->pip_share_set ? h->pip_share_set : walk_full - (h->lsi_share_blocks() <= 2 * h->cus ? 2 : 1) * h->cus;
+    const int share = h->pip_share_set ? h->pip_share_set : walk_full - (walk_share_of_this_pair <= 2 * h->cus ? 2 : 1) * h->cus;
     walk_blocks = share < h->max_blocks ? share : h->max_blocks;
   }
   if (aux && h->lsi_shared) h->last_pip_share = max_blocks;  // (overwritten below when the walk runs)
@@ -1898,6 +1912,12 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
       h->exact_rot = (h->exact_rot + 1) % 3;
       // the exact kernel two queries back: the last reader of this list set, and of the count word this walk clears for the next
       if (h->exact_recorded[h->exact_buf]) RJ_HIP(h, hipStreamWaitEvent(st, h->ev_exact_done[h->exact_buf], 0));
+      // ... and the LAST query's, if this one writes the same output arrays: its exact kernel still stores into them while this
+      // walk would (two queries in flight over one array is the caller's rule to keep -- every host wrapper here reuses one array:
+      // such a pair simply runs one after the other, as without the option)
+      if (h->exact_last >= 0 && h->exact_recorded[h->exact_last] &&
+          (h->exact_out_closest == (const void*) closest_eid_dev || (face_id_dev && h->exact_out_face == (const void*) face_id_dev)))
+        RJ_HIP(h, hipStreamWaitEvent(st, h->ev_exact_done[h->exact_last], 0));
     }
     w.todo = h->todo[li]; w.todo_mask = h->todo_mask[li];
     if (!w.group_lanes) w.group_lanes = pip_walk_group_lanes(n, w.bvh.top, h->cus);
@@ -1919,7 +1939,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
       RJ_HIP(h, launch_pip_strip(st, w, walk_blocks, h->cus));
     } else if (two) {
       if (aux && h->lsi_shared && !h->pip_share_set)
-        walk_blocks = h->cus * pip_walk2_blocks_beside(w.bvh.top, h->lsi_share_blocks() / h->cus < 1 ? 1 : h->lsi_share_blocks() / h->cus, wp);
+        walk_blocks = h->cus * pip_walk2_blocks_beside(w.bvh.top, walk_share_of_this_pair / h->cus < 1 ? 1 : walk_share_of_this_pair / h->cus, wp);
       RJ_HIP(h, launch_pip_walk2(st, w, walk_blocks, h->cus, h->stats_on, wp));
       h->last_walk_points = wp;
     } else {
@@ -1957,6 +1977,7 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
       RJ_HIP(h, hipEventRecord(h->ev_exact_done[h->exact_buf], h->exact_stream));
       h->exact_recorded[h->exact_buf] = true;
       h->exact_last = h->exact_buf;
+      h->exact_out_closest = closest_eid_dev; h->exact_out_face = face_id_dev;
       h->exact_buf ^= 1;
       h->exact_pending = true;
     } else {

@@ -72,6 +72,36 @@ def test_steps_in_flight_equal_synchronous_queries(concurrent):
     h.close()
 
 
+def test_queries_that_share_their_output_arrays_run_one_after_the_other():
+    """Round 5's advisor: with "pip_exact_stream" 1 the walk of query k + 1 ran beside the exact kernel of query k, and both
+    store into closest / face -- every host wrapper here hands every query ONE array.  The handle now remembers the last
+    query's arrays and makes such a pair wait: different point ranges into one array, all in flight, then the array holds the
+    LAST query's answers and nothing of the earlier ones."""
+    h, b, q = _setup()
+    steps, m = 8, q.n_points * 3 // 5
+    cap = int(0.5 * (b.n_edges + q.n_edges))
+    pairs = [h.alloc(8 * cap) for _ in range(2)]
+    c, f = h.alloc(4 * m), h.alloc(4 * m)
+    h.set_option("pip_walk", 2)
+    rng = _ranges(q, steps, m)
+    h.pip_query(0, 1, None, rng[-1][0], m, c, f)
+    want = (c.to_host(np.uint32, m).copy(), f.to_host(np.int32, m).copy())
+    h.set_option("pip_concurrent", 1)
+    h.set_option("pip_exact_stream", 1)
+    for rep in range(3):
+        for k, (p0, n) in enumerate(rng):
+            h.lsi_query_async(0, 1, 0, q.n_edges, cap, pairs[k % 2])
+            h.pip_query(0, 1, None, p0, n, c, f, sync=False)
+            h.lsi_count_async(k % 2)
+            if k > 0:
+                h.lsi_count_wait(1 - k % 2, cap)
+        h.lsi_count_wait((steps - 1) % 2, cap)
+        h.sync()
+        assert np.array_equal(c.to_host(np.uint32, m), want[0]), rep
+        assert np.array_equal(f.to_host(np.int32, m), want[1]), rep
+    h.close()
+
+
 def test_rejects_other_values():
     h, _, _ = _setup((8, 20), (9, 14))
     with pytest.raises(_capi.RayJoinError):
