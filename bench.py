@@ -503,7 +503,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         b_pip = 16 * n_p_loc + 32 * n_r + 4 * n_p_loc + 4 * n_p_loc  # + face ids
         # PMC evidence (tools/profile_run.sh + tools/pmc_summary.py): quoted only for the headline
         # workload and only while it was measured on exactly these kernel sources
-        traffic, sq, prof_note = {}, {}, None
+        traffic, sq, prof_note, fetch_cal = {}, {}, None, None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         is_headline = headline and world == 1 and args.scale == 1.0 and not args.emulate_shard and (base_name, query_name) == ("USCounty", "BlockGroup")
         shared_sq = {}
@@ -516,11 +516,13 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                     prof_note = "profiles/traffic.json is stale (measured on other kernel sources): traffic not quoted"
             elif is_headline:
                 traffic, sq, prof_note = doc.get("traffic", {}), doc.get("sq", {}), "profiles/%s_* (counter passes: each kernel alone on its full grid)" % doc.get("tag")
+                fetch_cal = doc.get("fetch_calibration")
                 # (the same kernels on the grids of the shared schedule -- k_lsi2 on 512 blocks, the walk on 1 536 -- profiled one
                 #  after the other: rocprofv3 serialises the kernels of a counter pass, tools/regime_probe.py)
                 shared_sq = doc.get("sections", {}).get("shared", {}).get("sq", {})
             elif sec:  # (another pair with a section of its own: the ring-shaped ones)
                 traffic, sq, prof_note = sec.get("traffic", {}), sec.get("sq", {}), "profiles/%s_pmc_sections.csv, section %s_%s (each kernel alone on its full grid)" % (doc.get("tag"), base_name, query_name)
+                fetch_cal = doc.get("fetch_calibration")
         # (a base map of isolated rings has a column index: the first pass reads the point's strip instead of walking the tree)
         walk_name = "k_pip_strip" if state.get("columns") else ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk")
         pip_kernel = walk_name if state["two_pass"] else "k_pip"
@@ -538,6 +540,8 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
                  "algorithmic_bytes": b, "kernel_ms": round(ms, 4), "pmc_source": prof_note}
             c = sq.get(kern, {})
             alone_ms = lsi_alone_ms if name == "lsi" else (walk_alone_ms or pip_alone_ms)
+            if traffic.get(kern) and fetch_cal and kern == "k_pip_strip":
+                r["fetch_calibration"] = fetch_cal   # (scattered reads: what the doubled counter rests on)
             if traffic.get(kern):
                 # (the counter passes run each kernel alone on its full grid: price the bytes against THAT time)
                 r["traffic_frac"] = round(traffic[kern] / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)

@@ -160,13 +160,32 @@ def test_waterbodies_blockgroup_lsi_full_size_and_8_shards(oracle):
     assert len(want) == n > 1_000_000
     assert np.array_equal(want["eid"], got)
     assert np.array_equal(want["x_num"], xs["x_num"]) and np.array_equal(want["y_num"], xs["y_num"])
-    del m0, m1, want
+    del m1, want
     parts = []
     for c0, c1 in query.shard_chain_ranges(8):
         e0, e1 = query.chain_range_to_eids(c0, c1)
         k = h.lsi_query(0, 1, e0, e1, cap, pairs)
         parts.append(pairs.to_host(np.uint32, 2 * k).reshape(-1, 2))
     assert np.array_equal(oracle.sort_pairs(np.concatenate(parts)), got)
+    # Round 6: the PIP query of this pair on the path the handle CHOOSES for a map of short chains -- the column index
+    # (rj_get_plan says on what grounds), the steep blocks of the tree in their second order for the LSI query above -- every
+    # vertex of the query map against the oracle's grid, eids and face ids; then the same on the tree walk ("pip_columns" 0).
+    closest = h.alloc(4 * query.n_points)
+    faces = h.alloc(4 * query.n_points)
+    h.pip_query(0, 1, None, 0, query.n_points, closest, faces)
+    plan = h.get_plan()
+    assert plan["index"][0]["columns"] and "short chains" in plan["index"][0]["columns_why"] and plan["index"][0]["steep_blocks_sorted_by_y"]
+    assert plan["pip"]["first_pass"]["kernel"] == "k_pip_strip"
+    we = oracle.pip_grid(m0, 0, query.pts, 4096)
+    assert (we != 0xFFFFFFFF).sum() > query.n_points // 2
+    assert np.array_equal(we, closest.to_host(np.uint32))
+    assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
+    h.set_option("pip_columns", 0)
+    h.build_lbvh(0)
+    h.pip_query(0, 1, None, 0, query.n_points, closest, faces)
+    assert h.get_plan()["pip"]["first_pass"]["kernel"] == "k_pip_walk2" and not h.get_plan()["index"][0]["columns"]
+    assert np.array_equal(we, closest.to_host(np.uint32))
+    assert np.array_equal(m0.face_ids(we), faces.to_host(np.int32))
     h.close()
 
 

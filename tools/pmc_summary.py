@@ -5,7 +5,10 @@ sources it was measured on: bench.py quotes it only while that hash matches the 
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KB, and on gfx950
 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section;
-calibrated on k_build_segs in profiles/README.md).
+calibrated on k_build_segs in profiles/README.md) -- and, since round 6, calibrated on SCATTERED reads
+too (tools/fetch_calibrate.hip, profiles/r06_fetch_calibration.txt): a 4-, 8- or 16-byte read of a line
+nobody else reads moves the whole 128-byte line and is tallied as 64 bytes, two reads in the two halves
+of one line are ONE request: the factor 2 holds for k_pip_strip's access pattern as for a stream.
 
 usage: pmc_summary.py <tag> <fetch_dir> <write_dir> [<sq_dir> ...]
 (the optional SQ_* passes of tools/profile_run.sh go to profiles/<tag>_sq_counters.csv, k_lsi / k_pip only)
@@ -103,7 +106,10 @@ def main():
             f.write("%s,%s,%d,%.1f\n" % r)
     sys.path.insert(0, ROOT)
     from rayjoin_amd._capi import kernel_source_hash
-    doc = {"tag": tag, "kernel_source_hash": kernel_source_hash(), "traffic": traffic, "sq": sq, "sections": {}}
+    doc = {"tag": tag, "kernel_source_hash": kernel_source_hash(), "traffic": traffic, "sq": sq, "sections": {},
+           # (tools/fetch_calibrate.hip: what the factor 2 on FETCH_SIZE rests on for scattered reads)
+           "fetch_calibration": "x2: FETCH_SIZE tallies a 128-byte line as 64 bytes for streams AND for scattered 4/8/16-byte reads (one request per line touched, "
+                                "both halves of a line = one request): profiles/r06_fetch_calibration.txt"}
     if sections:
         with open(os.path.join(ROOT, "profiles", "%s_pmc_sections.csv" % tag), "w") as f:
             f.write("section,counter,kernel,dispatches,avg_value\n")
