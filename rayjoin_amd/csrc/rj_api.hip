@@ -1202,7 +1202,11 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     // the walk dropped for its overflowed lists in the step (3.64 ms against 2.7); runs of 32 sharing leaves in pairs
     // (1.46 slots) 1.31 / 2.37.  So: the cap follows the mean chain length, and a run that fills three quarters of its
     // cap keeps its leaf (k_pack_runs) -- twice the index there, the faster one.
-    uint32_t cap_edges = mm.nc && mm.ne / mm.nc < 16 ? 32 : 64;
+    // Round 6: that holds where upward rays walk the tree.  A map of short chains now gets the column index for them
+    // ("pip_columns"), its leaves serve LSI alone, and with the steep blocks in their second order ("leaf_ysort") the full
+    // run wins: WaterBodies x BlockGroup, runs of 32 / 48 / 64 -- step 2.11 / 2.05 / 2.01 ms, k_lsi2 alone 1.03 / 1.02 / 1.01,
+    // 2.12 / 1.45 / 1.12 slots per segment, first build 9.2 / 8.9 / 8.1 ms (profiles/r06_runcap_with_second_order.txt).
+    uint32_t cap_edges = mm.nc && mm.ne / mm.nc < 16 && h->pip_columns == 0 ? 32 : 64;
     if (h->debug_run_cap) cap_edges = (uint32_t) h->debug_run_cap;
     uint64_t max_pieces = 0, max_runs = 0;
     stitch_output_bounds(mm.nc, mm.ne, cap_edges, &max_pieces, &max_runs);

@@ -385,6 +385,9 @@ __global__ __launch_bounds__(256, 8) void k_pip_strip(PipArgs A) {
       done[p] = valid[p] && (cand_at[p] == cand_base[p] || sure_y0[p] != INT32_MIN);
       const uint32_t fill = (cand_at[p] - cand_base[p]) >> 6;
       sure_inf[p] = make_uint4(0u, 0xFFFFFFFFu, 0u, 0u);
+      // (round 6, timing only: with this one record read of a settled point left out -- wrong answers -- the pass took 1.31
+      //  instead of 1.44 ms on the lake-shaped pair, 1.11 / 1.30 lakes x parks, 0.81 / 0.96 on the WaterBodies lattice: the
+      //  ceiling of any layout that brings the record into the box's own line, 9-16 %; not built)
       if (done[p] && fill) sure_inf[p] = S.einfo[cand[cand_base[p]]];
       const bool listed = valid[p] && !done[p] && fill <= (uint32_t) kWalkList;
 #pragma unroll
