@@ -1253,7 +1253,11 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     }
     // a run longer than three quarters of the cap keeps its leaf to itself (a nearly full strip of one polyline gains
     // little from a tenant and its box would have to be computed); a shared leaf may be `spread` times as large as what it holds
-    const uint32_t solo_above = h->debug_pack_solo ? (uint32_t) h->debug_pack_solo : (mm.run_cap ? mm.run_cap : 64u) * 3 / 4;
+    // (a map of short closed RINGS keeps round 4's rule -- rings of more than 24 edges alone -- whatever the run cap: with the
+    //  cap's 48, the lake-shaped map packs to 1.23 slots per segment instead of 1.54 and k_lsi2 over it is 8 % slower, the
+    //  gaussian polygons 12 %)
+    const bool short_rings = mm.nc && mm.ne / mm.nc < 16 && 2 * mm.closed_chains >= mm.nc;
+    const uint32_t solo_above = h->debug_pack_solo ? (uint32_t) h->debug_pack_solo : (short_rings ? 24u : (mm.run_cap ? mm.run_cap : 64u) * 3 / 4);
     // (measured on the ring-shaped pairs, PIP query alone: 4 / 8 / 16 -> lake-shaped base 40.2 / 41.6 / 41.8 ms, lakes x
     //  parks 18.7 / 19.7 / 24.2, gaussian polygons 2.46 / 2.25 / 2.18: 8)
     const uint32_t spread = h->debug_pack_spread ? (uint32_t) h->debug_pack_spread : 8;
