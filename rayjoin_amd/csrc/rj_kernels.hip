@@ -834,7 +834,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
   const bool occ_usable = T.occ[(size_t) kOccDim * kOccRowWords] == 0;  // every base segment was rasterised
   const int stack_cap = STATS && A.stack_cap < kStackEntries ? A.stack_cap : kStackEntries;  // (lowered only by tests of the fault path, instrumented kernel)
   int np = 0, nh = 0;  // wave-uniform fill of L.pairs / L.hits
-  unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0;
+  unsigned long long st_leaf = 0, st_tests = 0, st_nodes = 0, st_box = 0, st_refined = 0, st_kept = 0;
   long long tk_node = 0, tk_leaf = 0, tk_head = 0, tk_sched = 0;  // STATS: cycle stamps
   const long long tk_begin = STATS ? clock64() : 0;
 
@@ -890,6 +890,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     // queries need, whatever the spatial coherence of the group.
     auto refine = [&](const QBox& b, uint64_t um) -> uint64_t {
       uint64_t keep = 0;
+      if (STATS) st_refined += (unsigned long long) __popcll(um);
       while (um) {
         const int c = __builtin_ctzll(um);
         um &= um - 1;
@@ -897,6 +898,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         const int32_t cx1 = bcast(b.x1, c), cy1 = bcast(b.y1, c);
         if (__ballot(boxes_overlap(qx0, qy0, qx1, qy1, cx0, cy0, cx1, cy1))) keep |= 1ull << c;
       }
+      if (STATS) st_kept += (unsigned long long) __popcll(keep);
       return keep;
     };
     int sp = 0;
@@ -1003,6 +1005,8 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
     atomicAdd(&A.stats[6], (unsigned long long) tk_leaf);  // includes the dense predicate phase
     atomicAdd(&A.stats[7], (unsigned long long) tk_head);  // group load + union box + top level
     atomicAdd(&A.stats[10], (unsigned long long) tk_sched);
+    atomicAdd(&A.stats[11], st_refined);  // children that overlap the group's box and were tested against every query ...
+    atomicAdd(&A.stats[12], st_kept);     // ... and those some query overlaps (pushed)
     atomicMax(&A.stats[9], (unsigned long long) tk_total);
   }
 }

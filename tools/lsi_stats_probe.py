@@ -26,10 +26,12 @@ for ysort in (0, 1):
     h.set_option("stats", 1)
     h.lsi_query(0, 1, 0, q.n_edges, cap, pairs)
     s = h.last_stats()
+    raw = h.last_stats_raw()
     tot = max(1, s["cyc_total"])
     print(json.dumps({"pair": a.base + " x " + a.query, "leaf_ysort": ysort, "k_lsi2_ms": round(min(ms), 4), "hits": n, "groups_of_64": groups,
                       "per_group": {"leaf_blocks": round(s["leaf_blocks"] / groups, 3), "scan_steps": round(s["leaf_box_tests"] / groups, 3),
-                                    "exact_tests": round(s["exact_tests"] / groups, 3), "nodes": round(s["nodes_expanded"] / groups, 3)},
+                                    "exact_tests": round(s["exact_tests"] / groups, 3), "nodes": round(s["nodes_expanded"] / groups, 3),
+                                    "children_refined": round(raw[11] / groups, 3), "children_kept": round(raw[12] / groups, 3)},
                       "steps_per_leaf_block": round(s["leaf_box_tests"] / max(1, s["leaf_blocks"]), 2),
                       "cycles_frac": {"node": round(s["cyc_node"] / tot, 3), "leaf_and_predicate": round(s["cyc_leaf"] / tot, 3),
                                       "head": round(s["cyc_drain"] / tot, 3), "sched": round(s["cyc_sched"] / tot, 3)}}))
