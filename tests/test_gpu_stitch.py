@@ -27,7 +27,7 @@ def reference_runs(L, pts, row_index, cap):
     return pb[:npc.value], pl[:npc.value], rf[:nr.value + 1]
 
 
-def device_runs(pts, row_index, cap=0):
+def device_runs(pts, row_index, cap=0, columns=-1):
     pts = np.ascontiguousarray(pts, dtype=np.int64)
     row_index = np.ascontiguousarray(row_index, dtype=np.uint32)
     nc = len(row_index) - 1
@@ -35,6 +35,7 @@ def device_runs(pts, row_index, cap=0):
     try:
         h.upload_map(0, pts, row_index, np.zeros(nc, dtype=np.int64), np.ones(nc, dtype=np.int64))
         h.set_option("leaf_order", 1)
+        h.set_option("pip_columns", columns)
         if cap:
             h.set_debug_option("run_cap", cap)
         h.build_lbvh(0)
@@ -43,10 +44,13 @@ def device_runs(pts, row_index, cap=0):
         h.close()
 
 
-def default_cap(row_index):
+def default_cap(row_index, columns=-1):
+    """rj_build_lbvh: full runs of 64 edges -- since round 6 also where the chains average fewer than 16 edges, because such a
+    map gets the column index for its upward rays and the leaves serve LSI alone; runs of 32 there only when the caller
+    forbids that index ("pip_columns" 0) and the rays walk the tree"""
     eb = edge_begin(row_index)
     nc = len(eb) - 1
-    return 32 if nc and int(eb[-1]) // nc < 16 else 64  # (rj_build_lbvh: runs of 32 where the chains average fewer than 16 edges)
+    return 32 if columns == 0 and nc and int(eb[-1]) // nc < 16 else 64
 
 
 def same(ref, got, what):
@@ -65,6 +69,10 @@ def test_lattices(lib, G, k, cap):
     pts, rows = scaled(synth.lattice_map(G, k, 100 + G))
     got, (rounds, loops) = device_runs(pts, rows, cap)
     same(reference_runs(lib, pts, rows, cap or default_cap(rows)), got, ("lattice", G, k, cap))
+    if not cap and k < 16:   # (the short-chain lattice with the column index forbidden: the round-4 cap)
+        got0, _ = device_runs(pts, rows, 0, columns=0)
+        same(reference_runs(lib, pts, rows, default_cap(rows, 0)), got0, ("lattice, pip_columns 0", G, k))
+        assert default_cap(rows, 0) == 32
     assert loops == 0 and rounds <= 12
 
 
