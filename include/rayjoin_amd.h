@@ -308,7 +308,12 @@ int rj_last_stats(rj_handle h, uint64_t stats[16]);
  *                                             (k_pip_strip) instead of walking the tree.  -1 built where most chains are
  *                                             closed rings (lakes, parks: many small isolated faces) or where the map's
  *                                             chains are SHORT (mean below 16 edges: fat leaves; measured rule, round 6),
- *                                             0 never, 1 always.  rj_get_plan's index[].columns_why says which applied.
+ *                                             0 never, 1 always.  -1 also builds it LATER, at the first PIP query whose point
+ *                                             set (>= 2^22 points) turns out spatially incoherent -- the reference's
+ *                                             GeneratePIPQueries, uniform random points: the index answers every point on its
+ *                                             own where the tree walk first sorts the points and still shares little (8.4 M
+ *                                             random points: 1.07 -> 0.70 ms USCounty, 1.9 -> 0.43 LakesNA; that query pays the
+ *                                             build).  rj_get_plan's index[].columns_why says which rule applied.
  *                                             (Environment RJ_PIP_COLUMNS=0/1 changes the default: A/B runs.)
  * "leaf_ysort"       1 / 0                    the order inside a leaf block on the NEXT rj_build_lbvh.  Blocks lie sorted by x0 with
  *                                             a bucket table on x (what an upward ray needs).  1: a block TALLER than wide also gets

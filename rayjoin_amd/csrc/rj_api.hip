@@ -205,6 +205,13 @@ struct rj_handle_s {
   int debug_strip_shift = 0;                // the column index of the next build on strips of 2^this quanta (0: by the map)
   int debug_query_key_strips = 0;           // experiment: a re-ordered PIP query set over a column index is sorted strip-major (strip, then y), not by Morton key
   int order_strip_shift = 0;                // ... the strip width the next query-key pass sorts by (0: Morton keys)
+  // Round 6: a spatially INCOHERENT point set (the reference's GeneratePIPQueries: uniform random points) is answered by the
+  // column index -- every point on its own, nothing to share, nothing to sort -- built at the first such query of at least
+  // `lazy_columns_min` points when "pip_columns" is auto and the base map has none (8.4 M uniform random points, PIP query:
+  // USCounty 1.07 -> 0.70 ms, BlockGroup 1.63 -> 0.75, LakesNA 1.91 -> 0.43 -- tools/incoherent_columns_probe.py).
+  int debug_lazy_columns_min = 0;           // (0: 2^22 points)
+  bool lazy_columns_ok = false;             // set around the coherence estimate of a PIP query: "say so instead of sorting"
+  bool lazy_columns_want = false;           // ... the estimate's answer
   hipEvent_t ev[kNumTimers][2];
   bool ev_valid[kNumTimers] = {false};
   bool stats_on = false;
@@ -884,6 +891,7 @@ int rj_set_debug_option(rj_handle h, const char* name, int64_t value) {
       {"stack_cap", &h->debug_stack_cap, 1, 1 << 30},     // instrumented kernels: fewer traversal-stack entries (fault path)
       {"walk_stack", &h->debug_walk_stack, 0, 1 << 30},   // k_pip_walk*: fewer stack entries (groups that need more leave the walk)
       {"strip_shift", &h->debug_strip_shift, 0, 20},      // the column index on strips of 2^this quanta (0: chosen by the map; 15..20)
+      {"lazy_columns_min", &h->debug_lazy_columns_min, 0, 1 << 30},  // points from which an incoherent PIP query set makes the base map's column index (0: 2^22)
       {"query_key_strips", &h->debug_query_key_strips, 0, 1},  // "query_order" 2 over a column index: sort the points strip-major instead of by Morton key
       {"run_cap", &h->debug_run_cap, 0, 64},              // edges per polyline run of the next first build of a map (0: 64)
       {"pack_solo", &h->debug_pack_solo, 0, 64},          // a run longer than this never shares its leaf (0: 48)
@@ -1154,15 +1162,25 @@ static int build_strips(rj_handle h, BvhState& b, bool with_sky) {
     (void) hipFree(b.strip_info); (void) hipFree(b.strip_box);
     b.strip_info = nullptr; b.strip_box = nullptr; b.strip_cap = 0;
     const uint64_t cap = (uint64_t) total + total / 16;
-    if (int r = dev_alloc(h, &b.strip_box, cap)) return r;
-    if (int r = dev_alloc(h, &b.strip_info, cap)) return r;
+    int r = dev_alloc(h, &b.strip_box, cap);
+    if (!r) r = dev_alloc(h, &b.strip_info, cap);
+    if (r) {  // (no room for the lists: the caller's error only if the caller forced the index -- else the tree serves the map)
+      (void) hipFree(b.strip_box); (void) hipFree(b.strip_info);
+      b.strip_box = nullptr; b.strip_info = nullptr;
+      return forced ? r : RJ_OK;
+    }
     b.strip_cap = cap;
   }
   if (!b.strip_tall || b.strip_tab_shift > shift) {  // (narrower strips than the tables were made for)
     (void) hipFree(b.strip_tall); (void) hipFree(b.strip_ytab);
     b.strip_tall = nullptr; b.strip_ytab = nullptr; b.strip_tab_shift = 0;
-    if (int r = dev_alloc(h, &b.strip_tall, (uint64_t) strips)) return r;
-    if (int r = dev_alloc(h, &b.strip_ytab, ((uint64_t) strips << kStripYBits) + 1)) return r;
+    int r = dev_alloc(h, &b.strip_tall, (uint64_t) strips);
+    if (!r) r = dev_alloc(h, &b.strip_ytab, ((uint64_t) strips << kStripYBits) + 1);
+    if (r) {
+      (void) hipFree(b.strip_tall); (void) hipFree(b.strip_ytab);
+      b.strip_tall = nullptr; b.strip_ytab = nullptr;
+      return forced ? r : RJ_OK;
+    }
     b.strip_tab_shift = shift;
   }
   tb = sort_bytes;
@@ -1474,6 +1492,11 @@ static int order_caller_points(rj_handle h, const int64_t* pts, uint64_t n, cons
   }
   e->stamp = ++h->caller_clock;
   e->queries++;
+  if (incoherent && h->lazy_columns_ok) {  // (the caller builds the column index instead: no permutation, this query or later)
+    h->lazy_columns_want = true;
+    h->cur_caller = slot;
+    return RJ_OK;
+  }
   if (incoherent) {
     if (e->perm_cap < n) {
       RJ_HIP(h, hipStreamSynchronize(h->stream));  // (the old permutation may be in use)
@@ -1527,6 +1550,7 @@ static int maybe_order_queries(rj_handle h, bool points, const int64_t* pts, con
       if (cc) { cc->valid = true; cc->begin = key_begin; cc->n = n; cc->incoherent = incoherent; }
     }
     if (!incoherent) return RJ_OK;
+    if (h->lazy_columns_ok) { h->lazy_columns_want = true; return RJ_OK; }
   }
   rj_handle_s::OrdCache* oc = owner_map >= 0 ? &h->ordc[points ? 1 : 0][owner_map] : nullptr;
   if (oc && oc->valid && oc->begin == key_begin && oc->n == n) {  // sorted before, the map has not changed
@@ -1785,10 +1809,36 @@ int rj_pip_query_async(rj_handle h, int base_map_id, int query_map_id, const int
   const uint32_t* order = nullptr;
   // (a base map with a column index answers every point on its own -- nothing is shared between the points of a wave,
   //  so a scattered query set needs no re-ordering there)
-  const bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && (!h->stats_on || h->pip_walk == 2);
+  bool by_columns = h->bvh[base_map_id].strips_built && h->pip_walk != 0 && (!h->stats_on || h->pip_walk == 2);
   h->order_strip_shift = by_columns && h->debug_query_key_strips ? h->bvh[base_map_id].strip_shift : 0;
   if (by_columns && h->query_order != 2) { h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr; }
-  else if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) return r;
+  else {
+    // (an incoherent set of enough points over a base map without a column index, "pip_columns" auto: build the index now
+    //  instead of sorting the points -- see lazy_columns_ok)
+    const uint64_t lazy_min = h->debug_lazy_columns_min ? (uint64_t) h->debug_lazy_columns_min : (1ull << 22);
+    h->lazy_columns_ok = !by_columns && !h->bvh[base_map_id].strips_built && h->pip_columns < 0 && h->query_order == 1 && h->pip_walk != 0 &&
+                         !h->stats_on && n >= lazy_min;
+    h->lazy_columns_want = false;
+    if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) { h->lazy_columns_ok = false; return r; }
+    h->lazy_columns_ok = false;
+    if (h->lazy_columns_want) {
+      BvhState& bb = h->bvh[base_map_id];
+      RJ_HIP(h, hipStreamSynchronize(h->stream));  // (build_strips works on the main stream with the build's scratch words)
+      RJ_HIP(h, join_aux(h));
+      if (int r = build_strips(h, bb, false)) return r;
+      if (bb.strips_built) {
+        bb.columns_why = "built at the first PIP query over a spatially incoherent point set (uniform random points: every point on its own)";
+        by_columns = true;
+        co_reset(h);
+        h->plan.epoch++;
+        h->h_rest[0] = h->h_rest[1] = ~0ull;
+        h->walk_n[0] = h->walk_n[1] = 0;
+        h->last_ordered = false; h->order_fresh = false; h->cur_caller = -1; h->cur_order = nullptr;
+      } else if (int r = maybe_order_queries(h, true, pts, nullptr, 0, n, &order, pts_dev ? -1 : query_map_id, coh_begin)) {
+        return r;  // (no index after all -- a segment too wide, no memory: the permutation, as before)
+      }
+    }
+  }
   // "pip_concurrent": the kernel goes to the handle's second stream and runs BESIDE the LSI kernel
   // of the same step on the main stream (both only read the maps and the tree): with an LSI query in
   // flight on its reduced grid (lsi_launch), on 5 blocks per CU; otherwise on the full grid.  Not

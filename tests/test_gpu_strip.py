@@ -156,3 +156,45 @@ def test_the_strip_width_follows_the_map_and_never_changes_an_answer(oracle):
         assert entries[0] == entries[auto]
     finally:
         h.close()
+
+
+def test_an_incoherent_point_set_makes_the_column_index_at_its_first_query(oracle):
+    """Round 6: the reference's GeneratePIPQueries workload (run_query.cu:147-167: uniform random points) over a lattice of LONG
+    chains -- a map that gets no column index at its build.  The first PIP query whose point set turns out spatially incoherent
+    builds the index instead of sorting the points ("pip_columns" auto, enough points: "lazy_columns_min"), says so in the plan,
+    and every later query runs on it; results are the oracle's either way, for a caller-owned array and for the map's own
+    vertices; with "pip_columns" 0 nothing is built and the points go through the Morton permutation as before."""
+    ctx = maps.Context([synth.lattice_map(14, 60, 51), synth.lattice_map(30, 25, 52)]).load()
+    b, q = ctx.maps
+    ob = _omap(oracle, b)
+    rnd = np.ascontiguousarray(synth.generate_pip_queries(ctx.bb, ctx.scaling, 150000, 7))
+    want_rnd = oracle.pip_grid(ob, 0, rnd, 256)
+    want_own = oracle.pip_grid(ob, 0, q.pts, 256)
+    for columns in (-1, 0):
+        h = _capi.Handle(0)
+        try:
+            h.upload_map(0, b.pts, b.row_index, b.left, b.right)
+            h.upload_map(1, q.pts, q.row_index, q.left, q.right)
+            h.set_option("pip_columns", columns)
+            h.set_debug_option("lazy_columns_min", 100000)   # (the default, 2^22 points, scaled to this test: between the two query sets)
+            h.build_lbvh(0)
+            assert h.get_option("pip_columns_used0") == 0   # (long open chains: the tree walk at build time)
+            closest, faces = h.alloc(4 * len(rnd)), h.alloc(4 * len(rnd))
+            # the map's own vertices first: fewer points than the rule asks for, nothing changes
+            e, f = _pip(h, 0, None, q.n_points, h.alloc(4 * q.n_points), h.alloc(4 * q.n_points))
+            assert np.array_equal(e, want_own) and h.get_option("pip_columns_used0") == 0
+            d = h.alloc(16 * len(rnd)).from_host(rnd)
+            for rep in range(3):
+                e, f = _pip(h, 0, d, len(rnd), closest, faces)
+                assert np.array_equal(e, want_rnd), (columns, rep)
+                assert np.array_equal(f, ob.face_ids(want_rnd)), (columns, rep)
+                ix = h.get_plan()["index"][0]
+                if columns == -1:
+                    assert ix["columns"] and "incoherent" in ix["columns_why"] and h.get_option("pip_last_columns") == 1
+                    assert h.get_option("query_last_ordered") == 0
+                else:
+                    assert not ix["columns"] and h.get_option("pip_last_columns") == 0 and h.get_option("query_last_ordered") == 1
+            e, f = _pip(h, 0, None, q.n_points, h.alloc(4 * q.n_points), h.alloc(4 * q.n_points))
+            assert np.array_equal(e, want_own) and np.array_equal(f, ob.face_ids(want_own))
+        finally:
+            h.close()
