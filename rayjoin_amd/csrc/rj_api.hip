@@ -375,6 +375,8 @@ void free_bvh(BvhState& b) {
   b = BvhState();
 }
 
+static bool g_lsi_root_skip = true;  // (environment RJ_LSI_ROOT_SKIP=0: A/B runs)
+
 DeviceBvh bvh_view(const BvhState& b) {
   DeviceBvh d;
   d.sseg = b.sseg; d.seid = b.seid; d.sface = b.sface; d.box0 = b.box0; d.pmx1 = b.pmx1; d.xtab = b.xtab; d.ytab2 = b.ysort ? b.ytab2 : nullptr; d.occ = b.occ; d.sky = b.use_sky ? b.sky : nullptr;
@@ -383,6 +385,8 @@ DeviceBvh bvh_view(const BvhState& b) {
     d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
   }
   d.top = b.top; d.n0 = b.n0;
+  // (the LSI traversals start one level below a top level that holds a handful of nodes: rj_device.h DeviceBvh::lsi_root)
+  d.lsi_root = g_lsi_root_skip && b.top >= 2 && b.nlvl[b.top] <= 4 && b.nlvl[b.top - 1] <= 128 ? b.top - 1 : b.top;
   d.strips.ytab = b.strips_built ? b.strip_ytab : nullptr;
   d.strips.ebox = b.strip_box; d.strips.einfo = b.strip_info; d.strips.tall = b.strip_tall; d.strips.shift = b.strip_shift;
   return d;
@@ -529,6 +533,7 @@ int rj_create(int device_id, rj_handle* out) {
   if (const char* e = getenv("RJ_LSI_SEGMENTS")) h->lsi_segments = atoi(e) == 1 ? 1 : 2;  // (A/B runs)
   if (const char* e = getenv("RJ_WALK_POINTS")) h->walk_points = atoi(e) == 1 ? 1 : (atoi(e) == 4 ? 4 : 2);  // (A/B runs)
   if (const char* e = getenv("RJ_POINTS_SPLIT")) { const int v = atoi(e); h->points_split = v < -1 || v > 1 ? -1 : v; }  // (A/B runs, like the above)
+  if (const char* e = getenv("RJ_LSI_ROOT_SKIP")) g_lsi_root_skip = atoi(e) != 0;                                          // (A/B runs)
   if (const char* e = getenv("RJ_LEAF_YSORT")) h->leaf_ysort = atoi(e) == 0 ? 0 : 1;                                    // (A/B runs)
   if (const char* e = getenv("RJ_PIP_COLUMNS")) { const int v = atoi(e); h->pip_columns = v < -1 || v > 1 ? -1 : v; }    // (A/B runs: the column index on / off whatever the map)
   {

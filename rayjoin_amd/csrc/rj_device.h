@@ -125,6 +125,10 @@ struct DeviceBvh {
   const uint64_t* ord[kMaxLevels];  // where that word array of level l starts
   uint32_t nlvl[kMaxLevels];    // real node count per level
   int top;                // top level: nlvl[top] <= 64
+  // The level the LSI traversals START at (round 6): `top`, or top - 1 when the top level holds at most 4 nodes and the level
+  // below at most 128 -- a 64-ary tree over 27 M slots ends in a top level of TWO nodes, and expanding it is a dependent round
+  // trip to memory per query group for nothing: the <= 128 boxes of the level below are two loads side by side.
+  int lsi_root;
   uint64_t n0;            // real segment count
 };
 

@@ -871,7 +871,10 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       if (STATS) tk_head += clock64() - tkg;
       continue;
     }
-    const QBox root_box = T.lvl[T.top][lane];  // (requested beside the segments: one round trip, not two)
+    const int rl = T.lsi_root;                 // (the level the traversal starts at: DeviceBvh::lsi_root)
+    const uint32_t rn = T.nlvl[rl];            // (<= 128 nodes)
+    const QBox root_box = T.lvl[rl][lane];     // (requested beside the segments: one round trip, not two)
+    const QBox root_box2 = T.lvl[rl][(rn > 64 ? 64 : 0) + lane];
     {
       Seg s = Seg{0, 0, 0, 0};
       if (near) s = A.qseg[q];  // (a masked load: a lane the pre-filter cleared reads nothing)
@@ -902,12 +905,19 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       return keep;
     };
     int sp = 0;
-    {  // top level: <= 64 nodes, one per lane
+    {  // the starting level: <= 64 nodes, one per lane -- or <= 128, the second 64 likewise
       QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, T.top, b, (uint32_t) lane);
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, rl, b, (uint32_t) lane);
       sp = __popcll(m);
+      if (rn > 64) {
+        b = root_box2;
+        m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, rl, b, 64u + (uint32_t) lane);
+        sp += __popcll(m);
+      }
       wave_lds_fence();
     }
     if (STATS) tk_head += clock64() - tkg;
@@ -1066,7 +1076,10 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       for (int p = 0; p < 2; p++) near[p] = near[p] && occ_verdict_code(win[p], code[p]);
     }
     if (!__ballot(near[0] || near[1])) continue;  // both halves of the group are clear of the base map
-    const QBox root_box = T.lvl[T.top][lane];
+    const int rl = T.lsi_root;                 // (the level the traversal starts at: DeviceBvh::lsi_root)
+    const uint32_t rn = T.nlvl[rl];            // (<= 128 nodes)
+    const QBox root_box = T.lvl[rl][lane];
+    const QBox root_box2 = T.lvl[rl][(rn > 64 ? 64 : 0) + lane];
     {
       // (only the lanes the pre-filter let through read their segment -- two thirds of a passing group's lanes are clear of
       //  the base map too, and unmasked these loads doubled the kernel's traffic, 0.46 -> 0.93 GB -- but both sets' loads
@@ -1102,12 +1115,19 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       return keep;
     };
     int sp = 0;
-    {  // top level: <= 64 nodes, one per lane
+    {  // the starting level: <= 64 nodes, one per lane -- or <= 128, the second 64 likewise
       QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, T.top, b, (uint32_t) lane);
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, rl, b, (uint32_t) lane);
       sp = __popcll(m);
+      if (rn > 64) {
+        b = root_box2;
+        m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
+        if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, rl, b, 64u + (uint32_t) lane);
+        sp += __popcll(m);
+      }
       wave_lds_fence();
     }
     auto process = [&](uint32_t e, const QBox& b, const uint2& tab) {
