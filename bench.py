@@ -526,7 +526,9 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         # (a base map of isolated rings has a column index: the first pass reads the point's strip instead of walking the tree)
         walk_name = "k_pip_strip" if state.get("columns") else ("k_pip_walk2" if state["walk_points"] == 2 else "k_pip_walk")
         pip_kernel = walk_name if state["two_pass"] else "k_pip"
-        lsi_kernel = "k_lsi2" if state["lsi_segments"] == 2 else "k_lsi"
+        # (the kernel the handle's plan names: k_lsi2 / k_lsi, or -- a tree without a second order of its steep blocks: maps of closed
+        #  rings -- k_lsi2x / k_lsix, the same bodies with nothing of that order left in them)
+        lsi_kernel = ((state.get("plan") or {}).get("lsi") or {}).get("kernel") or ("k_lsi2" if state["lsi_segments"] == 2 else "k_lsi")
         # the PIP query's dominant kernel: its own HIP-event time in the timed steps (the three PIP kernels together: query_ms)
         pip_dom_ms = walk_k if walk_k else pip_k
         roof = {}

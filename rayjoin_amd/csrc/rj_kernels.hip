@@ -765,8 +765,11 @@ struct LsiWaveLds {
 
 // a stack entry of the LSI traversals: level above the index; a level-1 child (a leaf block) that is taller than wide and has
 // its second order goes as level 0 -- the kernels then read its table on y (k_build_leaves, rj_device.h leaf_is_steep)
+// (YS = false: the instantiation for trees without a second order -- maps of closed rings, "leaf_ysort" 0 -- in which nothing
+//  of it is left: those kernels are the round-5 ones)
+template <bool YS>
 __device__ __forceinline__ uint32_t lsi_entry(const DeviceBvh& T, int lvl, const QBox& b, uint32_t index) {
-  const bool by_y = lvl == 1 && T.ytab2 && leaf_is_steep(b.x0, b.y0, b.x1, b.y1);
+  const bool by_y = YS && lvl == 1 && T.ytab2 && leaf_is_steep(b.x0, b.y0, b.x1, b.y1);
   return ((uint32_t) (by_y ? 0 : lvl) << 28) | index;
 }
 
@@ -818,8 +821,8 @@ __device__ __forceinline__ void lsi_drain(LsiWaveLds& L, int& np, int& nh, int n
 
 // (96 SGPRs: above that the hardware admits one block per CU fewer than the occupancy query says --
 // MI355X_MICROARCH.md, "Residency" -- and this kernel lives on its resident waves)
-template <bool STATS>
-__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsi(LsiArgs A) {
+template <bool STATS, bool YS>
+__device__ __forceinline__ void lsi_body(const LsiArgs& A) {
   __shared__ LsiWaveLds lds[4];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
@@ -909,13 +912,13 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, rl, b, (uint32_t) lane);
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry<YS>(T, rl, b, (uint32_t) lane);
       sp = __popcll(m);
       if (rn > 64) {
         b = root_box2;
         m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, rl, b, 64u + (uint32_t) lane);
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry<YS>(T, rl, b, 64u + (uint32_t) lane);
         sp += __popcll(m);
       }
       wave_lds_fence();
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         // (cannot happen for a tree rj_build_lbvh accepted: kStackEntries covers the worst case, rj_device.h)
         if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, lvl - 1, b, idx * 64 + lane);
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry<YS>(T, lvl - 1, b, idx * 64 + lane);
         sp += __popcll(m);
         if (STATS) st_nodes++;
         wave_lds_fence();
@@ -946,7 +949,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
         const uint32_t slot0 = idx * 64;
         if (STATS) st_leaf++;
         // (the order the block is taken by: x, or -- a block taller than wide, pushed as level 0 -- its second one, y)
-        const bool ysort = lvl == 0;
+        const bool ysort = YS && lvl == 0;
         const uint32_t yslot = leaf_perm_of(tab);  // (ysort: the x-order slot of y-rank `lane`)
         const int32_t lx0 = wave_min(ysort ? b.y0 : b.x0), lx1 = wave_max(ysort ? b.y1 : b.x1);
         const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       // one address for both kinds of entry keeps the loads branch-free (the bucket table is only meaningful for leaves)
       const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
       b = src[c];
-      const uint2* tsrc = lvl == 0 ? T.ytab2 : T.xtab;  // (level 0 = a leaf block taken by its y order: lsi_entry)
+      const uint2* tsrc = YS && lvl == 0 ? T.ytab2 : T.xtab;  // (level 0 = a leaf block taken by its y order: lsi_entry)
       tab = tsrc[lvl > 1 ? (uint64_t) lane : c];
     };
     while (sp > 0) {
@@ -1027,7 +1030,8 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
 // x-range skips it.  The kernel is bound by its chain of dependent node fetches per group, so twice the queries per
 // chain is most of twice the throughput per wave.  Candidate pairs and hits go through the same LDS buffers
 // (they carry the query eid), so everything behind the traversal is k_lsi's.  Requires group_lanes == 64.
-__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsi2(LsiArgs A) {
+template <bool YS>
+__device__ __forceinline__ void lsi2_body(const LsiArgs& A) {
   __shared__ LsiWaveLds lds[4];
   const int lane = lane_id();
   const int wib = threadIdx.x >> 6;
@@ -1119,13 +1123,13 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       QBox b = root_box;
       uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
       if (!stack_has_room(0, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry(T, rl, b, (uint32_t) lane);
+      if ((m >> lane) & 1) L.stack[rank_below(m)] = lsi_entry<YS>(T, rl, b, (uint32_t) lane);
       sp = __popcll(m);
       if (rn > 64) {
         b = root_box2;
         m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, rl, b, 64u + (uint32_t) lane);
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry<YS>(T, rl, b, 64u + (uint32_t) lane);
         sp += __popcll(m);
       }
       wave_lds_fence();
@@ -1136,12 +1140,12 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       if (lvl > 1) {
         uint64_t m = refine(b, __ballot(overlap(b, gx0, gy0, gx1, gy1)));
         if (!stack_has_room(sp, __popcll(m), stack_cap, A.work_counter, kFaultLsiStack, lane)) m = 0;
-        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry(T, lvl - 1, b, idx * 64 + lane);
+        if ((m >> lane) & 1) L.stack[sp + rank_below(m)] = lsi_entry<YS>(T, lvl - 1, b, idx * 64 + lane);
         sp += __popcll(m);
         wave_lds_fence();
       } else {
         const uint32_t slot0 = idx * 64;
-        const bool ysort = lvl == 0;  // (the order the block is taken by: x, or -- taller than wide, pushed as level 0 -- y)
+        const bool ysort = YS && lvl == 0;  // (the order the block is taken by: x, or -- taller than wide, pushed as level 0 -- y)
         const uint32_t yslot = leaf_perm_of(tab);
         const int32_t lx0 = wave_min(ysort ? b.y0 : b.x0), lx1 = wave_max(ysort ? b.y1 : b.x1);
         const int sh = leaf_bucket_shift((uint32_t) (lx1 - lx0));
@@ -1178,7 +1182,7 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
       const uint64_t c = (uint64_t) (e & 0x0FFFFFFFu) * 64 + lane;
       const QBox* src = lvl > 1 ? T.lvl[lvl - 1] : T.box0;
       b = src[c];
-      const uint2* tsrc = lvl == 0 ? T.ytab2 : T.xtab;  // (level 0 = a leaf block taken by its y order: lsi_entry)
+      const uint2* tsrc = YS && lvl == 0 ? T.ytab2 : T.xtab;  // (level 0 = a leaf block taken by its y order: lsi_entry)
       tab = tsrc[lvl > 1 ? (uint64_t) lane : c];
     };
     while (sp > 0) {
@@ -1199,6 +1203,15 @@ __global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k
   if (nh >= 64) lsi_flush_hits<false>(L, nh, 64, A, lane);
   if (nh > 0) lsi_flush_hits<false>(L, nh, nh, A, lane);
 }
+
+// The kernels of the two bodies above: with the second order of steep leaf blocks (trees that have ytab2), and without --
+// maps of closed rings, "leaf_ysort" 0 -- where the compiler drops every trace of it.
+template <bool STATS>
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsi(LsiArgs A) { lsi_body<STATS, true>(A); }
+template <bool STATS>
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsix(LsiArgs A) { lsi_body<STATS, false>(A); }
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsi2(LsiArgs A) { lsi2_body<true>(A); }
+__global__ __launch_bounds__(256, 6) __attribute__((amdgpu_num_sgpr(96))) void k_lsi2x(LsiArgs A) { lsi2_body<false>(A); }
 
 // =============================================================================================
 // LSI intersection points (per hit only): rational point, clamp, narrowing store
@@ -2626,6 +2639,7 @@ static uint32_t pick_chunk_groups(uint32_t requested, uint32_t optimum) { return
 hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_blocks, int segs_per_lane, int* segs_used) {
   LsiArgs a = a_in;
   if (segs_used) *segs_used = 1;
+  const bool ys = a.bvh.ytab2 != nullptr;  // (the tree has a second order of its steep blocks: the kernels that use it)
   const void* k = stats ? (const void*) k_lsi<true> : (const void*) k_lsi<false>;
   static int res[2] = {0, 0};
   if (!res[stats]) res[stats] = resident_blocks(k, 1 << 20);
@@ -2643,8 +2657,8 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
     const uint64_t by_work = ngroups / (4 * 10);  // (the small-query rule below, for groups of twice the size)
     const int floor_blocks = 512 < grid ? 512 : grid;
     if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
-    note("k_lsi2", grid, 2);
-    hipLaunchKernelGGL(k_lsi2, dim3(grid), dim3(256), 0, st, a);
+    if (ys) { note("k_lsi2", grid, 2); hipLaunchKernelGGL(k_lsi2, dim3(grid), dim3(256), 0, st, a); }
+    else { note("k_lsi2x", grid, 2); hipLaunchKernelGGL(k_lsi2x, dim3(grid), dim3(256), 0, st, a); }
     if (segs_used) *segs_used = 2;
     return hipGetLastError();
   }
@@ -2661,9 +2675,11 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
   const int floor_blocks = 512 < grid ? 512 : grid;
   if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
   if (stats)
-    { note("k_lsi (instrumented)", grid, 1); hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a); }
-  else
+    { note("k_lsi (instrumented)", grid, 1); if (ys) hipLaunchKernelGGL(k_lsi<true>, dim3(grid), dim3(256), 0, st, a); else hipLaunchKernelGGL(k_lsix<true>, dim3(grid), dim3(256), 0, st, a); }
+  else if (ys)
     { note("k_lsi", grid, 1); hipLaunchKernelGGL(k_lsi<false>, dim3(grid), dim3(256), 0, st, a); }
+  else
+    { note("k_lsix", grid, 1); hipLaunchKernelGGL(k_lsix<false>, dim3(grid), dim3(256), 0, st, a); }
   return hipGetLastError();
 }
 

@@ -70,7 +70,7 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # round 3: the dominant kernel is the PIP walk; the line says what the number is (algorithmic bytes vs moved bytes)
-    assert r["kernel"] in ("k_pip_walk", "k_pip_walk2", "k_pip_strip", "k_lsi", "k_lsi2") and "query_ms" in (r if r["kernel"].startswith("k_pip_") else d["roofline_other"])
+    assert r["kernel"] in ("k_pip_walk", "k_pip_walk2", "k_pip_strip", "k_lsi", "k_lsi2", "k_lsix", "k_lsi2x") and "query_ms" in (r if r["kernel"].startswith("k_pip_") else d["roofline_other"])
     if r.get("traffic"):
         assert 0 < r["traffic_frac"] < 1 and r["limiter"] in ("valu-issue", "dependent-load latency", "hbm-traffic") and 0 < r["limiter_frac"] <= 1
     c = d["cpu_baseline"]
@@ -113,7 +113,7 @@ def test_traffic_file_matches_the_kernels_bench_reports():
     """profiles/traffic.json carries the PMC evidence bench.py quotes AND the hash of the kernel
     sources it was measured on; bench.py ignores it when that hash is not the tree's."""
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-    lsi_k, walk_k = ("k_lsi2" if "k_lsi2" in t["traffic"] else "k_lsi"), ("k_pip_walk2" if "k_pip_walk2" in t["traffic"] else "k_pip_walk")
+    lsi_k, walk_k = ("k_lsi2" if "k_lsi2" in t["traffic"] else "k_lsi"), ("k_pip_walk2" if "k_pip_walk2" in t["traffic"] else "k_pip_walk")  # (the headline's tree has the second order)
     assert {lsi_k, walk_k, "k_pip_exact"} <= set(t["traffic"]) and all(v > 0 for v in t["traffic"].values())
     assert len(t["kernel_source_hash"]) == 16 and t["tag"].startswith("r")
     for k in (lsi_k, walk_k):

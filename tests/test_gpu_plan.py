@@ -33,7 +33,7 @@ def test_plan_reports_and_rederives():
     n = h.lsi_query(0, 1, 0, q.n_edges, cap, pairs)
     h.pip_query(0, 1, None, 0, q.n_points, closest, faces)
     p = h.get_plan()
-    assert p["lsi"]["segments"] == q.n_edges and p["lsi"]["kernel"] in ("k_lsi", "k_lsi2") and p["lsi"]["blocks"] > 0
+    assert p["lsi"]["segments"] == q.n_edges and p["lsi"]["kernel"] in ("k_lsi", "k_lsi2", "k_lsix", "k_lsi2x") and p["lsi"]["blocks"] > 0
     assert not p["lsi"]["paired_with_pip"] and p["lsi"]["current"]
     assert p["pip"]["points"] == q.n_points and p["pip"]["stream"] == "main" and p["pip"]["passes"] == 3
     assert p["pip"]["first_pass"]["kernel"].startswith("k_pip_walk") and p["pip"]["second_pass"]["kernel"] == "k_pip_exact"

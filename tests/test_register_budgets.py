@@ -47,6 +47,7 @@ def test_the_shared_schedules_registers():
 
 def test_no_query_kernel_spills():
     k = _kernels()
-    for frag, vgprs in (("k_pip_walkILb0", 64), ("k_pip_exactE", 96), ("k_lsiILb0", 80), ("k_lsi_pointsE", 96)):
+    # (k_lsi2x / k_lsix: the LSI bodies instantiated without the second order of steep blocks -- maps of closed rings)
+    for frag, vgprs in (("k_pip_walkILb0", 64), ("k_pip_exactE", 96), ("k_lsiILb0", 80), ("k_lsixILb0", 80), ("k_lsi2xE", 80), ("k_lsi_pointsE", 96)):
         r = _one(k, frag)
         assert r["ScratchSize"] == 0 and r["VGPRs"] <= vgprs, (frag, r)

@@ -33,7 +33,7 @@ def short(name):
     return name.split("(")[0][:40]
 
 
-KERNELS = ("k_lsi", "k_lsi2", "k_pip_walk", "k_pip_walk2", "k_pip_walk4", "k_pip_strip", "k_pip_exact", "k_pip", "k_lsi_points", "k_lsi_points_gcd")
+KERNELS = ("k_lsi", "k_lsi2", "k_lsix", "k_lsi2x", "k_pip_walk", "k_pip_walk2", "k_pip_walk4", "k_pip_strip", "k_pip_exact", "k_pip", "k_lsi_points", "k_lsi_points_gcd")
 
 
 def full_grid(vals):

@@ -27,7 +27,7 @@ if a.regimes:
     for (n, b), v in sorted(acc.items()):
         print("%s,%d,%d,%.1f,%.1f,%.1f" % (n, b, len(v), sum(v) / len(v), min(v), max(v)))
 if a.steps:
-    starts = [i for i, r in enumerate(rows) if r[2] in (a.first, a.first + "2")]  # (k_lsi or k_lsi2, whichever the run used)
+    starts = [i for i, r in enumerate(rows) if r[2] in (a.first, a.first + "2", a.first + "x", a.first + "2x")]  # (k_lsi / k_lsi2 / their x-order-only forms, whichever the run used)
     if a.skip:
         starts = starts[:-a.skip]
     starts = starts[-a.steps - 1:] if len(starts) > a.steps else starts
