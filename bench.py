@@ -390,13 +390,17 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
     # 300 ms -- and the chip's clocks are still climbing when the timed steps begin (a fresh box, step by step: 0.79, 0.79,
     # 0.78 ... 0.74, 0.73 ms over the twenty).  Warm-up is meant in TIME: the same untimed steps go on until `--settle-ms` of
     # wall clock have passed since the warm-up began (default 40 ms; 0 = exactly W steps); the line says how many were added.
-    extra_warmup = 0
-    if warmup > 0 and args.settle_ms > 0 and world == 1:   # (N > 1: a step holds collectives -- every rank must run the same number of steps)
-        t_settle = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < t_settle and extra_warmup < 2000:
-            step(False)
-            extra_warmup += 1
-    state["extra_warmup"] = extra_warmup
+    def settle():
+        """untimed steps until --settle-ms of wall clock have passed (N = 1 only: a step of an N > 1 job holds collectives, every
+        rank must run the same number of steps); -> how many"""
+        extra = 0
+        if warmup > 0 and args.settle_ms > 0 and world == 1:
+            t_settle = time.perf_counter() + args.settle_ms * 1e-3
+            while time.perf_counter() < t_settle and extra < 2000:
+                step(False)
+                extra += 1
+        return extra
+    state["extra_warmup"] = settle()
     # the kernel schedule must be settled before anything is timed: four measured pairs do it, i.e. the fifth
     # warm-up step already runs the chosen schedule; with fewer warm-ups (or --serial-kernels) the line says so
     # (a re-ordered -- spatially shuffled -- query set is never paired: nothing to settle, one kernel after the other)
@@ -478,6 +482,7 @@ def run_workload(args, env, base_name, query_name, steps, warmup, headline, with
         state["caller_pts"] = cpts
         for _ in range(3):   # (first sight: one estimate with a round trip; then the settled path)
             step(False)
+        settle()             # (the same warm-up in time as the steps it is compared with: the digest above left the GPU idle)
         el_c = timed(steps)
         same = bool(torch.equal(closest[:p1 - p0], own))
         h.pip_query(0, 1, cpts, 0, p1 - p0, closest, faces)
