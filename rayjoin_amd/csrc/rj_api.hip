@@ -66,6 +66,7 @@ struct BvhState {
   uint4* strip_info = nullptr;   // [strip_cap] {slot, edge id, face id, 0} per entry
   uint2* strip_tall = nullptr;   // [strips] {tallest box, end of the strip's entries}
   int strip_shift = 0;           // a strip is 2^strip_shift quanta wide (chosen by the map's segments, build_strips)
+  uint32_t occ_permille = 0;     // set bits of the occupancy bitmap per thousand cells (the build counts them)
   bool ysort = false;            // the leaves' blocks may be ordered by y (k_build_leaves: blocks taller than wide)
   const char* columns_why = "";  // rj_get_plan: on what grounds the last build made (or did not make) the column index
   int strip_tab_shift = 0;       // ... and the width strip_tall / strip_ytab are allocated for (0: not yet)
@@ -384,7 +385,7 @@ DeviceBvh bvh_view(const BvhState& b) {
     d.lvl[l] = b.lvl[l]; d.nlvl[l] = (uint32_t) b.nlvl[l];
     d.ord[l] = b.lvl[l] ? reinterpret_cast<const uint64_t*>(b.lvl[l] + b.alloc[l]) : nullptr;
   }
-  d.top = b.top; d.n0 = b.n0;
+  d.top = b.top; d.n0 = b.n0; d.occ_permille = b.occ_permille;
   // (the LSI traversals start one level below a top level that holds a handful of nodes: rj_device.h DeviceBvh::lsi_root)
   d.lsi_root = g_lsi_root_skip && b.top >= 2 && b.nlvl[b.top] <= 4 && b.nlvl[b.top - 1] <= 128 ? b.top - 1 : b.top;
   d.strips.ytab = b.strips_built ? b.strip_ytab : nullptr;
@@ -696,6 +697,7 @@ int rj_get_option(rj_handle h, const char* name, int64_t* value) {
   else if (!strcmp(name, "skyline")) *value = h->skyline;
   else if (!strcmp(name, "pip_columns")) *value = h->pip_columns;
   else if (!strcmp(name, "leaf_ysort")) *value = h->leaf_ysort;
+  else if (!strcmp(name, "occ_permille0") || !strcmp(name, "occ_permille1")) *value = h->bvh[name[12] - '0'].occ_permille;
   else if (!strcmp(name, "leaf_ysort_used0") || !strcmp(name, "leaf_ysort_used1")) *value = h->bvh[name[15] - '0'].ysort ? 1 : 0;
   else if (!strcmp(name, "pip_columns_used0") || !strcmp(name, "pip_columns_used1")) *value = h->bvh[name[16] - '0'].strips_built ? 1 : 0;
   else if (!strcmp(name, "pip_column_entries0") || !strcmp(name, "pip_column_entries1")) *value = (int64_t) h->bvh[name[18] - '0'].strip_entries;
@@ -737,9 +739,9 @@ int rj_get_plan(rj_handle h, char* buf, size_t cap, size_t* need) {
   for (int m = 0; m < 2; m++) {
     const BvhState& b = h->bvh[m];
     add("%s{\"map\": %d, \"built\": %s, \"levels\": %d, \"slots\": %llu, \"leaves\": \"%s\", \"skyline\": %s, \"columns\": %s, \"column_shift\": %d, "
-        "\"steep_blocks_sorted_by_y\": %s, \"mean_chain_edges\": %.1f, \"slots_per_segment\": %.3f, \"columns_why\": \"",
+        "\"steep_blocks_sorted_by_y\": %s, \"occupancy_permille\": %u, \"mean_chain_edges\": %.1f, \"slots_per_segment\": %.3f, \"columns_why\": \"",
         m ? ", " : "", m, b.built ? "true" : "false", b.top, (unsigned long long) b.n0p, b.leaf_order == 1 ? "polyline runs" : "Hilbert neighbours",
-        b.use_sky ? "true" : "false", b.strips_built ? "true" : "false", b.strips_built ? b.strip_shift : 0, b.ysort ? "true" : "false",
+        b.use_sky ? "true" : "false", b.strips_built ? "true" : "false", b.strips_built ? b.strip_shift : 0, b.ysort ? "true" : "false", b.occ_permille,
         h->map[m].nc ? (double) h->map[m].ne / (double) h->map[m].nc : 0.0, b.n0 ? (double) b.n0p / (double) b.n0 : 0.0);
     for (const char* c = b.built ? b.columns_why : ""; *c; c++) { if (*c == '"') o += '\\'; o += *c; }  // (JSON string: quotes escaped)
     o += "\"}";
@@ -1437,8 +1439,10 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     RJ_HIP(h, launch_build_sky(h->stream, b.box0, b.seid, b.n0p, b.sky));
     b.use_sky = true;
   }
+  RJ_HIP(h, launch_occ_count(h->stream, b.occ, h->d_rest + 4));  // (how dense the pre-filter's bitmap is: DeviceBvh::occ_permille)
   toc(h, RJ_T_BUILD);
   RJ_HIP(h, hipStreamSynchronize(h->stream));
+  b.occ_permille = (uint32_t) (h->h_rest[4] * 1000ull / ((unsigned long long) kOccDim * kOccDim));
   b.built = true;
   co_reset(h);
   h->h_rest[0] = h->h_rest[1] = ~0ull;  // (a new index: the "auto" decision to drop the walk is taken again)

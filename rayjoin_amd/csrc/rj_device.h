@@ -46,6 +46,7 @@ constexpr int kOccShift = 19;                  // 31-bit quantised coordinate ->
 constexpr int kOccDim = 1 << (31 - kOccShift);  // 4096 x 4096 cells = 2 MiB of bits
 constexpr int kOccRowWords = kOccDim / 32;
 constexpr int kOccMaxCellsPerSeg = 4096;
+constexpr uint32_t kOccDensePermille = 300;  // from here on launch_lsi treats the map as one whose every query group traverses (measured on the stand-ins, set cells per thousand: USCounty 60, Zipcode 147, Gaussian5M 149, WaterBodiesLike 243, LakesLike 268 | BlockGroup 358, LakesNA 483, WaterBodies 571)
 // The SKYLINE of an indexed map (round 4): per x-bucket of 2^kSkyShift quanta, 1 + the highest quantised y of any
 // segment whose box touches the bucket (0: none does).  A query point that lies above it has NO edge above itself --
 // a certain miss of the upward ray, answered without a traversal.  Proving a miss is the one thing a box hierarchy is
@@ -129,6 +130,8 @@ struct DeviceBvh {
   // below at most 128 -- a 64-ary tree over 27 M slots ends in a top level of TWO nodes, and expanding it is a dependent round
   // trip to memory per query group for nothing: the <= 128 boxes of the level below are two loads side by side.
   int lsi_root;
+  // set bits of the occupancy bitmap per thousand cells (k_occ_count at the build): how little the LSI pre-filter can dismiss
+  uint32_t occ_permille;
   uint64_t n0;            // real segment count
 };
 

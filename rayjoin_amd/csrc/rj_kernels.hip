@@ -486,6 +486,23 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
   }
 }
 
+// How dense the occupancy bitmap is (round 6): one block counts its set bits into a mapped host word.  What the LSI
+// pre-filter can dismiss depends on it -- a third of the headline's query groups pass over USCounty's bitmap, nearly all
+// over a dense lattice's -- and launch_lsi sizes the grid of a SMALL query set by it (DeviceBvh::occ_permille).
+__global__ __launch_bounds__(1024) void k_occ_count(const uint32_t* __restrict__ occ, unsigned long long* __restrict__ out_mapped) {
+  __shared__ unsigned long long part[16];
+  unsigned long long c = 0;
+  for (uint32_t i = threadIdx.x; i < (uint32_t) kOccDim * kOccRowWords; i += 1024) c += (unsigned long long) __popc(occ[i]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int k = 0; k < 16; k++) t += part[k];
+    __hip_atomic_store(out_mapped, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // The skyline (maps of isolated rings that have no column index): every x-bucket a segment's box touches is at least as
 // high as the box.  A pass of its own over the built leaves' boxes -- inside k_build_leaves it was 0.96 of that kernel's
 // 2.19 ms on the lake-shaped map (an L2 look and sometimes an atomic per segment and bucket), paid by every build of a
@@ -2594,6 +2611,11 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
   return hipGetLastError();
 }
 
+hipError_t launch_occ_count(hipStream_t st, const uint32_t* occ, unsigned long long* out_mapped) {
+  hipLaunchKernelGGL(k_occ_count, dim3(1), dim3(1024), 0, st, occ, out_mapped);
+  return hipGetLastError();
+}
+
 hipError_t launch_build_sky(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* sky) {
   hipLaunchKernelGGL(k_build_sky, dim3(grid_for(n0p, 256, 8192)), dim3(256), 0, st, box0, seid, n0p, sky);
   return hipGetLastError();
@@ -2654,7 +2676,12 @@ hipError_t launch_lsi(hipStream_t st, const LsiArgs& a_in, bool stats, int max_b
     a.chunk_groups = 4;  // (128-segment groups: the same 8 x 64 positions per chunk)
     const uint64_t nchunks = (ngroups + a.chunk_groups - 1) / a.chunk_groups;
     int grid = grid_for(nchunks, 4, res2 < max_blocks ? res2 : max_blocks);
-    const uint64_t by_work = ngroups / (4 * 10);  // (the small-query rule below, for groups of twice the size)
+    // (the small-query rule below, for groups of twice the size: ten groups per resident wave -- tuned on the headline, where
+    //  two thirds of the groups are dismissed by the pre-filter.  Over a DENSE occupancy bitmap nearly every group traverses and
+    //  that is too few waves: five -- the 1/8 shard of WaterBodies x BlockGroup, k_lsi2 0.248 -> 0.200 ms, the shard's
+    //  pipelined step 0.354 -> 0.323)
+    const uint64_t per_wave = a.bvh.occ_permille >= kOccDensePermille ? 5 : 10;
+    const uint64_t by_work = ngroups / (4 * per_wave);
     const int floor_blocks = 512 < grid ? 512 : grid;
     if (by_work < (uint64_t) grid) grid = by_work > (uint64_t) floor_blocks ? (int) by_work : floor_blocks;
     if (ys) { note("k_lsi2", grid, 2); hipLaunchKernelGGL(k_lsi2, dim3(grid), dim3(256), 0, st, a); }
