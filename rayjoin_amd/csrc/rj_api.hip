@@ -196,6 +196,7 @@ struct rj_handle_s {
   int points_split = -1;                   // "lsi_points_split": -1 by the last count (default), 0 never, 1 always
   int last_points_split = 0;               // what the last records launch did
   unsigned long long* d_stats = nullptr;    // [16]
+  unsigned long long* d_occ_part = nullptr; // [16] partial sums of the occupancy bitmap's count (k_occ_count)
   unsigned long long* h_pinned = nullptr;   // [32] pinned read-back area
   // Traversal-stack fault words, [0] LSI [1] PIP: pinned host memory the kernels write directly
   // (never in practice: rj_device.h), so every sync point can check them without a copy
@@ -554,6 +555,7 @@ int rj_create(int device_id, rj_handle* out) {
   }
   bool ok = hipMalloc((void**) &h->d_counter, kCounterBytes) == hipSuccess &&
             hipMalloc((void**) &h->d_stats, 128) == hipSuccess &&
+            hipMalloc((void**) &h->d_occ_part, 128) == hipSuccess &&
             hipHostMalloc((void**) &h->h_pinned, 256) == hipSuccess &&
             hipHostMalloc((void**) &h->h_fault, 64, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**) &h->d_fault, h->h_fault, 0) == hipSuccess &&
@@ -598,7 +600,7 @@ int rj_destroy(rj_handle h) {
   (void) hipStreamSynchronize(h->exact_stream);
   for (int i = 0; i < 2; i++) { free_map(h->map[i]); free_bvh(h->bvh[i]); free_grid(h->grid[i]); }
   for (int k = 0; k < 2; k++) for (int i = 0; i < 2; i++) (void) hipFree(h->ordc[k][i].perm);
-  (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
+  (void) hipFree(h->d_counter); (void) hipFree(h->d_stats); (void) hipFree(h->d_occ_part); (void) hipHostFree(h->h_pinned); (void) hipHostFree(h->h_fault);
   (void) hipFree(h->slow_list);
   (void) hipHostFree(h->h_est);
   for (int k = 0; k < rj_handle_s::kCallerSets; k++) (void) hipFree(h->caller[k].perm);
@@ -1439,7 +1441,7 @@ int rj_build_lbvh(rj_handle h, int base_map_id) {
     RJ_HIP(h, launch_build_sky(h->stream, b.box0, b.seid, b.n0p, b.sky));
     b.use_sky = true;
   }
-  RJ_HIP(h, launch_occ_count(h->stream, b.occ, h->d_rest + 4));  // (how dense the pre-filter's bitmap is: DeviceBvh::occ_permille)
+  RJ_HIP(h, launch_occ_count(h->stream, b.occ, h->d_occ_part, h->d_rest + 4));  // (how dense the pre-filter's bitmap is: DeviceBvh::occ_permille)
   toc(h, RJ_T_BUILD);
   RJ_HIP(h, hipStreamSynchronize(h->stream));
   b.occ_permille = (uint32_t) (h->h_rest[4] * 1000ull / ((unsigned long long) kOccDim * kOccDim));

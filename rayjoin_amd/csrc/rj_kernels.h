@@ -152,7 +152,7 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
                                const uint32_t* piece_len, const uint32_t* run_first, const uint32_t* run_len, const uint32_t* leaf_first, uint64_t nblocks,
                                uint64_t n_parent_alloc, Seg* sseg, uint32_t* seid, int32_t* sface, QBox* box0,
                                int32_t* pmx1, uint2* xtab, QBox* lvl1, uint32_t* occ, uint2* ytab2 = nullptr);
-hipError_t launch_occ_count(hipStream_t st, const uint32_t* occ, unsigned long long* out_mapped);
+hipError_t launch_occ_count(hipStream_t st, const uint32_t* occ, unsigned long long* part16, unsigned long long* out_mapped);
 hipError_t launch_build_sky(hipStream_t st, const QBox* box0, const uint32_t* seid, uint64_t n0p, uint32_t* sky);
 hipError_t launch_sibling_order(hipStream_t st, const QBox* box, uint64_t n_alloc, uint64_t* higher);
 hipError_t launch_reduce_level(hipStream_t st, const QBox* child, uint64_t n_child_alloc, QBox* parent,

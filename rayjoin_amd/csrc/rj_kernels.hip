@@ -489,18 +489,25 @@ __global__ __launch_bounds__(256) void k_build_leaves(const Seg* __restrict__ se
 // How dense the occupancy bitmap is (round 6): one block counts its set bits into a mapped host word.  What the LSI
 // pre-filter can dismiss depends on it -- a third of the headline's query groups pass over USCounty's bitmap, nearly all
 // over a dense lattice's -- and launch_lsi sizes the grid of a SMALL query set by it (DeviceBvh::occ_permille).
-__global__ __launch_bounds__(1024) void k_occ_count(const uint32_t* __restrict__ occ, unsigned long long* __restrict__ out_mapped) {
-  __shared__ unsigned long long part[16];
+__global__ __launch_bounds__(1024) void k_occ_count(const uint32_t* __restrict__ occ, unsigned long long* __restrict__ part) {
+  // (sixteen blocks, a partial sum each: one block over the whole 2 MiB was 0.23 ms -- half of USCounty's rebuild)
+  __shared__ unsigned long long ws[16];
   unsigned long long c = 0;
-  for (uint32_t i = threadIdx.x; i < (uint32_t) kOccDim * kOccRowWords; i += 1024) c += (unsigned long long) __popc(occ[i]);
+  const uint32_t words = (uint32_t) kOccDim * kOccRowWords;
+  for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < words; i += gridDim.x * 1024u) c += (unsigned long long) __popc(occ[i]);
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
-    for (int k = 0; k < 16; k++) t += part[k];
-    __hip_atomic_store(out_mapped, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int k = 0; k < 16; k++) t += ws[k];
+    part[blockIdx.x] = t;
   }
+}
+__global__ void k_occ_sum(const unsigned long long* __restrict__ part, int n, unsigned long long* __restrict__ out_mapped) {
+  unsigned long long t = 0;
+  for (int k = 0; k < n; k++) t += part[k];
+  __hip_atomic_store(out_mapped, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // The skyline (maps of isolated rings that have no column index): every x-bucket a segment's box touches is at least as
@@ -2611,8 +2618,9 @@ hipError_t launch_build_leaves(hipStream_t st, const Seg* seg, const uint32_t* o
   return hipGetLastError();
 }
 
-hipError_t launch_occ_count(hipStream_t st, const uint32_t* occ, unsigned long long* out_mapped) {
-  hipLaunchKernelGGL(k_occ_count, dim3(1), dim3(1024), 0, st, occ, out_mapped);
+hipError_t launch_occ_count(hipStream_t st, const uint32_t* occ, unsigned long long* part16, unsigned long long* out_mapped) {
+  hipLaunchKernelGGL(k_occ_count, dim3(16), dim3(1024), 0, st, occ, part16);
+  hipLaunchKernelGGL(k_occ_sum, dim3(1), dim3(1), 0, st, part16, 16, out_mapped);
   return hipGetLastError();
 }
 
